@@ -1,0 +1,407 @@
+"""TEST INFRASTRUCTURE -- CPU restatement (oracle) of the reference hot path.
+
+This file is the *checker*, never the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.
+It restates, in a functional style over a plain ``state_dict`` (name -> tensor),
+what the reference's ``nn.Module`` graphs compute, using stock fp32 ``torch`` CPU
+ops.  It is pinned against the imported reference modules by
+``oracle/make_golden.py`` (run in the build container, where ``/root/reference``
+exists) and against the committed fixtures in ``tests/golden`` by
+``tests/test_oracle_golden.py``.
+
+Reference citations (relative to /root/reference):
+  residual block            model/FSRnet.py:75-98
+  hourglass BasicBlock      model/FSRnet.py:105-135
+  Hourglass                 model/FSRnet.py:176-215
+  Course_SR_Network         model/FSRnet.py:308-340
+  Fine_SR_Encoder           model/FSRnet.py:342-379
+  Prior_Estimation_Network  model/FSRnet.py:381-426
+  Fine_SR_Decoder           model/FSRnet.py:428-459
+  bottleneck_IR(_SE)        SUPER_RESOLUTION/model/model_irse.py:23-91
+  Backbone                  SUPER_RESOLUTION/model/model_irse.py:129-189
+  ResNet / BasicBlock       model/resnet.py:18-47,152-225
+  losses                    loss/loss.py:7-62
+  pair distance + ROC       utils/utils.py:14-87
+  KD step                   distill_main.py:42-96
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+# ----------------------------------------------------------------------------- helpers
+
+def _inorm(sd, p, x):
+    """InstanceNorm2d, no running stats; affine iff the key exists (model/FSRnet.py:81,112)."""
+    w = sd.get(p + ".weight")
+    b = sd.get(p + ".bias")
+    return F.instance_norm(x, None, None, w, b, True, 0.0, EPS)
+
+
+def _bnorm(sd, p, x, train, new_stats=None):
+    """BatchNorm (1d/2d), eps 1e-5, momentum 0.1.  In train mode the updated running
+    statistics are written to ``new_stats`` (dict) instead of mutating ``sd``."""
+    rm, rv = sd[p + ".running_mean"], sd[p + ".running_var"]
+    if train:
+        rm, rv = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], train, BN_MOMENTUM, EPS)
+    if train and new_stats is not None:
+        new_stats[p + ".running_mean"] = rm
+        new_stats[p + ".running_var"] = rv
+    return y
+
+
+def _conv(sd, p, x, stride=1, padding=0):
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride, padding)
+
+
+# ----------------------------------------------------------------------------- FSRNet (root)
+
+def residual_block(sd, p, x):
+    """PReLU_out(IN2(conv2(PReLU(IN1(conv1(x))))) + x) -- model/FSRnet.py:90-98."""
+    y = _conv(sd, p + ".conv1", x, 1, 1)
+    y = F.prelu(_inorm(sd, p + ".in1", y), sd[p + ".relu.weight"])
+    y = _conv(sd, p + ".conv2", y, 1, 1)
+    y = _inorm(sd, p + ".in2", y) + x
+    return F.prelu(y, sd[p + ".relu_out.weight"])
+
+
+def _shared_trunk(sd, p, x, times=3, blocks=3):
+    """The same ``blocks``-block Sequential applied ``times`` times (model/FSRnet.py:331-333)."""
+    for _ in range(times):
+        for j in range(blocks):
+            x = residual_block(sd, f"{p}.{j}", x)
+    return x
+
+
+def coarse_sr(sd, x, p=""):
+    """Course_SR_Network.forward -> (feat64, coarse_img) (model/FSRnet.py:328-340)."""
+    y = F.prelu(_inorm(sd, p + "bn_mid", _conv(sd, p + "conv_input", x, 1, 1)), sd[p + "relu.weight"])
+    y = _shared_trunk(sd, p + "residual", y)
+    y = _inorm(sd, p + "bn_mid", y)
+    return y, _conv(sd, p + "conv_mid", y, 1, 1)
+
+
+def fine_encoder(sd, x, p=""):
+    """Fine_SR_Encoder.forward (model/FSRnet.py:359-379): conv7x7 s4 -> IN -> PReLU -> trunk -> conv_end -> IN -> PReLU."""
+    y = F.prelu(_inorm(sd, p + "bn_mid", _conv(sd, p + "conv_input", x, 4, 3)), sd[p + "relu.weight"])
+    y = _shared_trunk(sd, p + "residual", y)
+    return F.prelu(_inorm(sd, p + "bn_mid", _conv(sd, p + "conv_end", y, 1, 1)), sd[p + "relu.weight"])
+
+
+def hg_basic_block(sd, p, x):
+    """Hourglass BasicBlock (model/FSRnet.py:119-135): non-affine IN, one PReLU used twice."""
+    a = sd[p + ".relu.weight"]
+    y = F.prelu(_inorm(sd, p + ".bn1", _conv(sd, p + ".conv1", x, 1, 1)), a)
+    y = _inorm(sd, p + ".bn2", _conv(sd, p + ".conv2", y, 1, 1)) + x
+    return F.prelu(y, a)
+
+
+def _hg_seq(sd, p, x, nblocks=2):
+    for j in range(nblocks):
+        x = hg_basic_block(sd, f"{p}.{j}", x)
+    return x
+
+
+def hourglass(sd, p, x, n):
+    """Hourglass._hour_glass_forward (model/FSRnet.py:200-212), depth n (keys hg.<n-1>.<branch>)."""
+    up1 = _hg_seq(sd, f"{p}.{n - 1}.0", x)
+    low = F.max_pool2d(x, 2, stride=2)
+    low = _hg_seq(sd, f"{p}.{n - 1}.1", low)
+    low = hourglass(sd, p, low, n - 1) if n > 1 else _hg_seq(sd, f"{p}.{n - 1}.3", low)
+    low = _hg_seq(sd, f"{p}.{n - 1}.2", low)
+    return up1 + F.interpolate(low, scale_factor=2)
+
+
+def prior_net(sd, x, p=""):
+    """Prior_Estimation_Network.forward -> (feat128, landmark97, parsing11) (model/FSRnet.py:408-426)."""
+    y = F.prelu(_inorm(sd, p + "bn", _conv(sd, p + "conv", x, 4, 3)), sd[p + "relu.weight"])
+    for j in range(3):
+        y = residual_block(sd, f"{p}residual.{j}", y)
+    y = hourglass(sd, p + "hg.hg", y, 2)
+    return y, _conv(sd, p + "fc_landmark", y), _conv(sd, p + "fc", y)
+
+
+def fine_decoder(sd, x, p=""):
+    """Fine_SR_Decoder.forward (model/FSRnet.py:448-459)."""
+    a = sd[p + "relu.weight"]
+    y = F.prelu(_inorm(sd, p + "bn_mid", _conv(sd, p + "conv_input", x, 1, 1)), a)
+    y = F.conv_transpose2d(y, sd[p + "deconv.weight"], sd[p + "deconv.bias"], stride=4, padding=2, output_padding=1)
+    y = F.prelu(_inorm(sd, p + "bn_mid", y), a)
+    y = _shared_trunk(sd, p + "residual", y)
+    y = _inorm(sd, p + "bn_mid", y)
+    return _conv(sd, p + "conv_out", y, 1, 1)
+
+
+def fhn_forward(sds, lr_img):
+    """112x112 composition of the four generators as SUPER_RESOLUTION/train_FHN.py:274-279 does:
+    coarse_img -> {prior, encoder} -> cat(prior_feat, enc_feat) -> decoder.
+    ``sds`` = dict(coarse=..., prior=..., encoder=..., decoder=...) of state_dicts."""
+    _, coarse_img = coarse_sr(sds["coarse"], lr_img)
+    pf, lmk, par = prior_net(sds["prior"], coarse_img)
+    ef = fine_encoder(sds["encoder"], coarse_img)
+    sr = fine_decoder(sds["decoder"], torch.cat((pf, ef), 1))
+    return sr, coarse_img, lmk, par
+
+
+# ----------------------------------------------------------------------------- IR / IR-SE backbone
+
+IR50_UNITS = ((64, 64, 3), (64, 128, 4), (128, 256, 14), (256, 512, 3))  # model_irse.py:104-110
+IR50_STAGE_ENDS = (2, 6, 20, 23)
+
+
+def ir50_blocks():
+    out = []
+    for cin, depth, n in IR50_UNITS:
+        out.append((cin, depth, 2))
+        out += [(depth, depth, 1)] * (n - 1)
+    return out
+
+
+def ir_block(sd, p, x, cin, depth, stride, se, train, new_stats=None):
+    """bottleneck_IR / bottleneck_IR_SE (model_irse.py:49-91)."""
+    if cin == depth:
+        sc = x[:, :, ::stride, ::stride] if stride > 1 else x  # MaxPool2d(1, stride)
+    else:
+        sc = _bnorm(sd, p + ".shortcut_layer.1", _conv(sd, p + ".shortcut_layer.0", x, stride), train, new_stats)
+    r = _bnorm(sd, p + ".res_layer.0", x, train, new_stats)
+    r = F.prelu(_conv(sd, p + ".res_layer.1", r, 1, 1), sd[p + ".res_layer.2.weight"])
+    r = _bnorm(sd, p + ".res_layer.4", _conv(sd, p + ".res_layer.3", r, stride, 1), train, new_stats)
+    if se:
+        s = r.mean((2, 3), keepdim=True)
+        s = torch.sigmoid(_conv(sd, p + ".res_layer.5.fc2", F.relu(_conv(sd, p + ".res_layer.5.fc1", s))))
+        r = r * s
+    return r + sc
+
+
+def ir_input_layer(sd, x, train, new_stats=None, p=""):
+    y = _bnorm(sd, p + "input_layer.1", _conv(sd, p + "input_layer.0", x, 1, 1), train, new_stats)
+    return F.prelu(y, sd[p + "input_layer.2.weight"])
+
+
+def ir_backbone(sd, x, se=False, train=False, drop_mask=None, taps=(), new_stats=None, p=""):
+    """Backbone.forward (model_irse.py:167-172).  ``drop_mask`` (N x 512 x 7 x 7 of {0,1}) replaces the
+    Dropout(0.5) RNG in train mode (kept entries are scaled by 2); None disables dropout.
+    Returns (embedding, [tapped body outputs in order of ``taps`` (block indices)])."""
+    y = ir_input_layer(sd, x, train, new_stats, p)
+    tapped = []
+    for i, (cin, depth, stride) in enumerate(ir50_blocks()):
+        y = ir_block(sd, f"{p}body.{i}", y, cin, depth, stride, se, train, new_stats)
+        if i in taps:
+            tapped.append(y)
+    y = _bnorm(sd, p + "output_layer.0", y, train, new_stats)
+    if train and drop_mask is not None:
+        y = y * drop_mask * 2.0
+    y = F.linear(y.flatten(1), sd[p + "output_layer.3.weight"], sd[p + "output_layer.3.bias"])
+    return _bnorm(sd, p + "output_layer.4", y, train, new_stats), tapped
+
+
+def ir_teacher5(sd, x, se=False):
+    """The 5-output teacher wrapper distill_main.py:59 expects (not in the reference tree):
+    eval-mode IR-50 with taps after body blocks 2/6/20/23."""
+    e, t = ir_backbone(sd, x, se=se, train=False, taps=IR50_STAGE_ENDS)
+    return (e, *t)
+
+
+# ----------------------------------------------------------------------------- ResNet-34
+
+R34_LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))  # model/resnet.py:160-163,231-236
+
+
+def resnet34(sd, x, train=False, new_stats=None, p=""):
+    """ResNet.forward -> (emb, x1, x2, x3, x4) (model/resnet.py:208-225; max-pool skipped :212)."""
+    y = F.relu(_bnorm(sd, p + "bn1", _conv(sd, p + "conv1", x, 2, 3), train, new_stats))
+    feats = []
+    inpl = 64
+    for li, (planes, n, stride) in enumerate(R34_LAYERS, start=1):
+        for b in range(n):
+            q = f"{p}layer{li}.{b}"
+            st = stride if b == 0 else 1
+            o = F.relu(_bnorm(sd, q + ".bn1", _conv(sd, q + ".conv1", y, st, 1), train, new_stats))
+            o = _bnorm(sd, q + ".bn2", _conv(sd, q + ".conv2", o, 1, 1), train, new_stats)
+            if b == 0 and (st != 1 or inpl != planes):
+                y = _bnorm(sd, q + ".downsample.1", _conv(sd, q + ".downsample.0", y, st), train, new_stats)
+            y = F.relu(o + y)
+        inpl = planes
+        feats.append(y)
+    z = _bnorm(sd, p + "bn_o1", y, train, new_stats)
+    z = F.linear(z.flatten(1), sd[p + "fc.weight"], sd[p + "fc.bias"])
+    return (_bnorm(sd, p + "bn_o2", z, train, new_stats), *feats)
+
+
+# ----------------------------------------------------------------------------- losses
+
+def mse97(a, b):
+    """MSELossFunc (loss/loss.py:13-15)."""
+    return ((a.float() - b.float()) ** 2).mean() * 97.0
+
+
+def landmark_loss(pred, target):
+    """MSELoss_Landmark (loss/loss.py:20-32): channel-summed prediction vs ONE heat-map."""
+    return ((pred.sum(1).float() - target.float()) ** 2).mean() * 97.0
+
+
+def nll2d(logits, target):
+    """CrossEntropyLoss2d (loss/loss.py:61-62)."""
+    return F.nll_loss(F.log_softmax(logits, 1), torch.squeeze(target))
+
+
+def cross_entropy(logits, target):
+    """nn.CrossEntropyLoss of the teacher trainer (main.py:132, train_teacher_model.py:190)."""
+    return F.cross_entropy(logits, target)
+
+
+def mmd_gaussian(a, b, sigmas=(1.0, 2.0, 4.0, 8.0, 16.0)):
+    """Build-defined (reference imports an undefined ``MMD``, Face_Hallucination_sub_Net.py:25):
+    biased Gaussian-kernel MMD^2 between two N x D batches, multi-bandwidth.  fp64."""
+    a, b = a.double(), b.double()
+    z = torch.cat((a, b), 0)
+    d2 = torch.cdist(z, z).pow(2)
+    k = sum(torch.exp(-d2 / (2.0 * s * s)) for s in sigmas)
+    n = a.shape[0]
+    return k[:n, :n].mean() + k[n:, n:].mean() - 2.0 * k[:n, n:].mean()
+
+
+def arcface_logits(emb, weight, target, s=64.0, m=0.5):
+    """Build-defined ArcFace head (absent from the reference; l2_norm as model_irse.py:16-20):
+    logits = s*cos(theta + m*onehot), easy-margin off, with the usual cos(pi-m) fallback.  fp64 in."""
+    e = emb / emb.norm(2, 1, True)
+    w = weight / weight.norm(2, 1, True)
+    cos = (e @ w.t()).clamp(-1.0, 1.0)
+    sin = (1.0 - cos * cos).clamp_min(0).sqrt()
+    cm, sm = float(np.cos(m)), float(np.sin(m))
+    th, mm = float(np.cos(np.pi - m)), float(np.sin(np.pi - m) * m)
+    phi = torch.where(cos > th, cos * cm - sin * sm, cos - mm)
+    onehot = F.one_hot(target, weight.shape[0]).bool()
+    return s * torch.where(onehot, phi, cos)
+
+
+# ----------------------------------------------------------------------------- evaluation (utils/utils.py)
+
+def pair_dist(e1, e2):
+    """utils/utils.py:41-43: squared L2 per pair (fp32 in, numpy)."""
+    d = np.subtract(e1, e2)
+    return np.sum(np.square(d), 1)
+
+
+def confusion_at(thresholds, dist, issame):
+    """Vectorised calculate_accuracy (utils/utils.py:14-24) over all thresholds at once.
+    predict_same = dist < thr.  Returns integer arrays (tp, fp, tn, fn) of len(thresholds)."""
+    thresholds = np.asarray(thresholds)
+    issame = np.asarray(issame).astype(bool)
+    ds = np.sort(dist[issame])
+    dd = np.sort(dist[~issame])
+    tp = np.searchsorted(ds, thresholds, side="left").astype(np.int64)
+    fp = np.searchsorted(dd, thresholds, side="left").astype(np.int64)
+    fn = ds.size - tp
+    tn = dd.size - fp
+    return tp, fp, tn, fn
+
+
+def rates_from_counts(tp, fp, tn, fn, n):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tpr = np.where(tp + fn == 0, 0.0, tp.astype(np.float64) / np.maximum(tp + fn, 1))
+        fpr = np.where(fp + tn == 0, 0.0, fp.astype(np.float64) / np.maximum(fp + tn, 1))
+    acc = (tp + tn).astype(np.float64) / float(n)
+    return tpr, fpr, acc
+
+
+def calculate_roc(thresholds, e1, e2, issame, folds):
+    """calculate_roc (utils/utils.py:26-87) with the fold index arrays given explicitly
+    (the reference draws them from an unseeded sklearn KFold) and the unused
+    O(P^2 log P) ``margin_list`` (:47-49) dropped.  ``folds`` = list of (train_idx, test_idx)."""
+    thresholds = np.asarray(thresholds)
+    issame = np.asarray(issame)
+    dist = pair_dist(e1, e2)
+    k, t = len(folds), len(thresholds)
+    tprs, fprs = np.zeros((k, t)), np.zeros((k, t))
+    acc, best = np.zeros(k), np.zeros(k)
+    for f, (tr, te) in enumerate(folds):
+        a = rates_from_counts(*confusion_at(thresholds, dist[tr], issame[tr]), len(tr))[2]
+        bi = int(np.argmax(a))
+        best[f] = thresholds[bi]
+        tprs[f], fprs[f], acc_te = rates_from_counts(*confusion_at(thresholds, dist[te], issame[te]), len(te))
+        acc[f] = acc_te[bi]
+    return tprs.mean(0), fprs.mean(0), acc.mean(), best
+
+
+# ----------------------------------------------------------------------------- step restatements
+
+def params_of(sd, skip_buffers=True):
+    """Trainable leaves of a state_dict: everything except BN buffers."""
+    return {k: v for k, v in sd.items()
+            if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var"))}
+
+
+def with_grad(sd):
+    """Clone a state_dict making every trainable tensor a grad-requiring leaf."""
+    out = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if v.dtype.is_floating_point and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+        out[k] = v
+    return out
+
+
+def grads_of(loss, sd, retain=False):
+    """d loss / d theta for every trainable leaf; None where unused."""
+    names = [k for k, v in sd.items() if v.requires_grad]
+    gs = torch.autograd.grad(loss, [sd[k] for k in names], retain_graph=retain, allow_unused=True)
+    return dict(zip(names, gs))
+
+
+def coarse_step_grads(sd, lr_img, hr_img):
+    """BASELINE config 1: L = 12 * mse97(coarse, hr) (Face_Hallucination_sub_Net.py:225)."""
+    sd = with_grad(sd)
+    _, coarse = coarse_sr(sd, lr_img)
+    loss = 12.0 * mse97(coarse, hr_img)
+    return loss.detach(), coarse.detach(), grads_of(loss, sd)
+
+
+def teacher_step_grads(sd, x, target, se=True, drop_mask=None):
+    """train_teacher_model.py:189-202 with the IR-(SE-)50 as ``model``: CE on the 512-d output."""
+    sd = with_grad(sd)
+    stats = {}
+    emb, _ = ir_backbone(sd, x, se=se, train=True, drop_mask=drop_mask, new_stats=stats)
+    loss = cross_entropy(emb, target)
+    return loss.detach(), emb.detach(), grads_of(loss, sd), stats
+
+
+def kd_step_grads(t_sd, s_sd, a_sd, x, se=False):
+    """distill_main.py:59-70 at pre-step weights: student loss -> student grads; assistant loss ->
+    assistant grads (the intended pairing; :74's second student step is a reference bug)."""
+    with torch.no_grad():
+        t = ir_teacher5(t_sd, x, se=se)
+    s_sd, a_sd = with_grad(s_sd), with_grad(a_sd)
+    st_s, st_a = {}, {}
+    s = resnet34(s_sd, x, train=True, new_stats=st_s)
+    a = resnet34(a_sd, x, train=True, new_stats=st_a)
+    s_loss = F.mse_loss(s[0], t[0])
+    a_loss = sum(F.mse_loss(t[k] - s[k], a[k]) for k in range(1, 5)) + F.mse_loss(t[0] - s[0], a[0])
+    gs = grads_of(s_loss, s_sd, retain=True)
+    ga = grads_of(a_loss, a_sd)
+    return (s_loss.detach(), a_loss.detach()), gs, ga, (st_s, st_a), [v.detach() for v in s], [v.detach() for v in a]
+
+
+def fhn_step_grads(sds, lr_img, hr_img, heatmap, parsing):
+    """One forward; per-(loss_k, theta_k) gradients at pre-step weights, discriminator
+    terms dropped (112x112 composition): L_coarse = 12*mse97(coarse,hr) -> coarse;
+    L_enc = 10*mse97(sr,hr) -> encoder; L_prior = mse97(sr,hr)+lmk+CE -> prior; L_dec = 10*mse97(sr,hr) -> decoder."""
+    sds = {k: with_grad(v) for k, v in sds.items()}
+    sr, coarse, lmk, par = fhn_forward(sds, lr_img)
+    pix = mse97(sr, hr_img)
+    losses = {
+        "coarse": 12.0 * mse97(coarse, hr_img),
+        "encoder": 10.0 * pix,
+        "prior": pix + landmark_loss(lmk, heatmap) + nll2d(par, parsing),
+        "decoder": 10.0 * pix,
+    }
+    grads = {k: grads_of(losses[k], sds[k], retain=True) for k in ("coarse", "encoder", "prior", "decoder")}
+    outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach())
+    return {k: v.detach() for k, v in losses.items()}, outs, grads

@@ -1,0 +1,299 @@
+"""TEST INFRASTRUCTURE -- golden-fixture generator.  Runs ONLY in the build container.
+
+Imports the reference's own pure-PyTorch modules from /root/reference on CPU, loads
+deterministic weights (oracle/detgen.py) into them, runs them on seeded synthetic inputs,
+and
+  (1) asserts the CPU restatement in oracle/cpu_ref.py reproduces every output/gradient
+      (tight fp32 tolerance) -- this is what *pins* the oracle, and
+  (2) writes small fixtures (full tensors when small, digests otherwise) to tests/golden/.
+
+The reference never travels to the GPU box; only these data files do.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import cpu_ref as R  # noqa: E402
+from oracle import detgen as G  # noqa: E402
+from oracle.digest import digest  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+TOL = 2e-4  # restatement-vs-reference tolerance, relative to max-abs of the reference tensor
+
+
+def ref_import(name):
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    return importlib.import_module(name)
+
+
+def close(a, b, what, tol=TOL, floor=1e-12):
+    a, b = a.detach().double(), b.detach().double()
+    scale = max(float(b.abs().max()), floor)
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, f"{what}: restatement differs from reference by {err:.3e} (rel to max-abs)"
+    return err
+
+
+def pack(store, name, t):
+    t = t.detach()
+    if t.numel() <= 16384:
+        store[name] = t.numpy().astype(np.float32 if t.dtype.is_floating_point else np.int64)
+    else:
+        store[name + "@digest"] = digest(t)
+
+
+def load_det(module, seed=0):
+    sd = G.det_state_dict(module.state_dict(), seed)
+    module.load_state_dict(sd)
+    return sd
+
+
+def grads_ref(loss, module, retain=False):
+    names, ps = zip(*module.named_parameters())
+    gs = torch.autograd.grad(loss, ps, retain_graph=retain, allow_unused=True)
+    return dict(zip(names, gs))
+
+
+def compare_grads(gref, gmine, what, store=None, prefix="", keep=()):
+    worst = 0.0
+    # gradients that are mathematically zero (e.g. a conv bias feeding an InstanceNorm) are pure rounding
+    # noise on both sides: compare them against a floor tied to the module's largest gradient instead
+    gscale = max(float(g.abs().max()) for g in gref.values() if g is not None)
+    for k, g in gref.items():
+        if g is None:
+            assert gmine[k] is None, f"{what}: {k} should receive no gradient"
+            continue
+        worst = max(worst, close(gmine[k], g, f"{what} grad {k}", 5e-4, floor=1e-2 * gscale))
+    if store is not None:
+        store[prefix + "none_grad_keys"] = np.array(sorted(k for k, g in gref.items() if g is None))
+        for k in keep:
+            pack(store, prefix + "grad/" + k, gref[k])
+    return worst
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    keys = {}
+    t0 = time.time()
+
+    # ------------------------------------------------------------------ FSRNet root (a1-a6, a14, a16)
+    fsr = ref_import("model.FSRnet")
+    loss_mod = ref_import("loss.loss")
+    n = 2
+    hr = G.synth_faces(n, 112, seed=1)
+    lr = G.synth_lr_from_hr(hr)
+    hm = G.synth_heatmap(n, 28, 97, 1.3, seed=2)
+    par = G.synth_parsing(n, 28, 11, seed=2)
+
+    nets = dict(coarse=fsr.Course_SR_Network(), encoder=fsr.Fine_SR_Encoder(),
+                prior=fsr.Prior_Estimation_Network(), decoder=fsr.Fine_SR_Decoder())
+    sds = {}
+    for name, m in nets.items():
+        sds[name] = load_det(m)
+        keys["fsrnet_root." + name] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    st = {}
+    # module-level forwards
+    feat, coarse = nets["coarse"](lr)
+    f2, c2 = R.coarse_sr(sds["coarse"], lr)
+    close(f2, feat, "coarse feat"); close(c2, coarse, "coarse img")
+    pack(st, "coarse/feat", feat); pack(st, "coarse/img", coarse)
+    enc = nets["encoder"](hr)
+    close(R.fine_encoder(sds["encoder"], hr), enc, "encoder"); pack(st, "encoder/out", enc)
+    pf, lmk, prs = nets["prior"](hr)
+    pf2, lmk2, prs2 = R.prior_net(sds["prior"], hr)
+    close(pf2, pf, "prior feat"); close(lmk2, lmk, "prior lmk"); close(prs2, prs, "prior parsing")
+    pack(st, "prior/feat", pf); pack(st, "prior/landmark", lmk); pack(st, "prior/parsing", prs)
+    dec_in = torch.cat((pf, enc), 1)
+    dec = nets["decoder"](dec_in)
+    close(R.fine_decoder(sds["decoder"], dec_in), dec, "decoder"); pack(st, "decoder/out", dec)
+
+    # config 1 step: 12 * mse97(coarse, hr) -> coarse net grads
+    l_c1 = 12.0 * loss_mod.MSELossFunc()(coarse, hr)
+    g_ref = grads_ref(l_c1, nets["coarse"], retain=True)
+    l_mine, _, g_mine = R.coarse_step_grads(sds["coarse"], lr, hr)
+    close(l_mine, l_c1, "c1 loss", 1e-5)
+    compare_grads(g_ref, g_mine, "c1", st, "c1/", keep=("conv_input.weight", "conv_mid.weight", "bn_mid.weight",
+                                                       "bn_mid.bias", "relu.weight", "residual.1.conv2.weight",
+                                                       "residual.0.relu_out.weight", "residual.2.in1.weight"))
+    st["c1/loss"] = np.float64(l_c1.item())
+
+    # composed FHN step (train_FHN.py:274-279 composition + Face_Hallucination_sub_Net.py:225-247 loss map)
+    for m in nets.values():
+        m.zero_grad()
+    _, coarse = nets["coarse"](lr)
+    pf, lmk, prs = nets["prior"](coarse)
+    ef = nets["encoder"](coarse)
+    sr = nets["decoder"](torch.cat((pf, ef), 1))
+    mse = loss_mod.MSELossFunc()
+    pix = mse(sr, hr)
+    losses = dict(coarse=12.0 * mse(coarse, hr), encoder=10.0 * pix,
+                  prior=pix + loss_mod.MSELoss_Landmark()(lmk, hm) + loss_mod.CrossEntropyLoss2d()(prs, par),
+                  decoder=10.0 * pix)
+    l2, outs2, g2 = R.fhn_step_grads(sds, lr, hr, hm, par)
+    close(outs2["sr"], sr, "fhn sr"); close(outs2["landmark"], lmk, "fhn lmk"); close(outs2["parsing"], prs, "fhn parsing")
+    pack(st, "fhn/sr", sr); pack(st, "fhn/coarse", coarse); pack(st, "fhn/landmark", lmk); pack(st, "fhn/parsing", prs)
+    keep = dict(coarse=("conv_input.weight", "residual.2.conv1.weight"),
+                encoder=("conv_input.weight", "conv_end.weight", "relu.weight"),
+                prior=("conv.weight", "fc.weight", "fc_landmark.bias", "hg.hg.0.3.1.conv2.weight", "hg.hg.1.0.0.relu.weight"),
+                decoder=("conv_input.weight", "deconv.weight", "deconv.bias", "conv_out.weight", "bn_mid.weight"))
+    for k in ("coarse", "encoder", "prior", "decoder"):
+        close(l2[k], losses[k], f"fhn loss {k}", 1e-5)
+        st[f"fhn/loss/{k}"] = np.float64(losses[k].item())
+        compare_grads(grads_ref(losses[k], nets[k], retain=True), g2[k], f"fhn {k}", st, f"fhn/{k}/", keep[k])
+    np.savez_compressed(os.path.join(OUT, "fsrnet_root.npz"), **st)
+    print(f"[golden] fsrnet_root ok ({time.time() - t0:.1f}s)")
+
+    # ------------------------------------------------------------------ IR-50 / IR-SE-50 (a10, a11, a13, a19)
+    irse = ref_import("SUPER_RESOLUTION.model.model_irse")
+    gdc = ref_import("SUPER_RESOLUTION.model.GroupDepthConv")
+    st = {}
+    x = G.synth_faces(4, 112, seed=1, start=100)
+    tgt = G.synth_labels(4, 512, seed=2)
+    for tag, ctor, se in (("ir50", irse.IR_50, False), ("irse50", irse.IR_SE_50, True)):
+        net = ctor([112, 112])
+        sd = load_det(net)
+        keys[tag] = {k: list(v.shape) for k, v in net.state_dict().items()}
+        net.eval()
+        with torch.no_grad():
+            emb = net(x[:2])
+            feats, _, last, _ = gdc.FeatureExtractor()(net.input_layer(x[:2]), ["2", "6", "20", "21", "22", "23"], net.body)
+            e2, taps = R.ir_backbone(sd, x[:2], se=se, train=False, taps=(2, 6, 20, 21, 22, 23))
+        close(e2, emb, f"{tag} eval emb")
+        for i, k in enumerate(("2", "6", "20", "21", "22", "23")):
+            close(taps[i], feats[k], f"{tag} tap {k}")
+            pack(st, f"{tag}/eval/tap{k}", feats[k])
+        pack(st, f"{tag}/eval/emb", emb)
+        # train step: CE on the 512-d output (train_teacher_model.py:189-202); Dropout RNG pinned by p=0
+        net.train()
+        net.output_layer[1].p = 0.0
+        out = net(x)
+        loss = F.cross_entropy(out, tgt)
+        g_ref = grads_ref(loss, net)
+        l_m, e_m, g_m, stats = R.teacher_step_grads(sd, x, tgt, se=se, drop_mask=None)
+        close(e_m, out, f"{tag} train emb"); close(l_m, loss, f"{tag} train loss", 1e-5)
+        compare_grads(g_ref, g_m, f"{tag} train", st, f"{tag}/train/",
+                      keep=("input_layer.0.weight", "input_layer.1.weight", "input_layer.2.weight",
+                            "body.0.res_layer.1.weight", "body.3.shortcut_layer.0.weight", "body.3.shortcut_layer.1.bias",
+                            "body.23.res_layer.4.weight", "output_layer.4.weight", "output_layer.3.bias")
+                      + (("body.7.res_layer.5.fc1.weight", "body.7.res_layer.5.fc2.weight") if se else ()))
+        pack(st, f"{tag}/train/emb", out)
+        st[f"{tag}/train/loss"] = np.float64(loss.item())
+        new_sd = net.state_dict()
+        for k in ("input_layer.1.running_mean", "input_layer.1.running_var", "body.23.res_layer.4.running_var",
+                  "output_layer.4.running_mean"):
+            close(stats[k], new_sd[k], f"{tag} {k}")
+            pack(st, f"{tag}/train/stats/{k}", new_sd[k])
+        print(f"[golden] {tag} ok ({time.time() - t0:.1f}s)")
+    np.savez_compressed(os.path.join(OUT, "irse.npz"), **st)
+
+    # ------------------------------------------------------------------ ResNet-34 + KD step (a12, a18)
+    resnet = ref_import("model.resnet")
+    st = {}
+    x = G.synth_faces(2, 112, seed=1, start=200)
+    teacher = irse.IR_50([112, 112]); t_sd = load_det(teacher, 0); teacher.eval()
+    student = resnet.ResNet_34(); s_sd = load_det(student, 1)
+    assistant = resnet.ResNet_34(); a_sd = load_det(assistant, 2)
+    keys["resnet34"] = {k: list(v.shape) for k, v in student.state_dict().items()}
+    student.eval()
+    with torch.no_grad():
+        ref_out = student(x)
+        mine = R.resnet34(s_sd, x, train=False)
+    for i, nm in enumerate(("emb", "x1", "x2", "x3", "x4")):
+        close(mine[i], ref_out[i], f"resnet34 eval {nm}")
+        pack(st, f"r34/eval/{nm}", ref_out[i])
+    student.train(); assistant.train()
+    with torch.no_grad():
+        feats, _, last, _ = gdc.FeatureExtractor()(teacher.input_layer(x), ["2", "6", "20", "23"], teacher.body)
+        t_emb = teacher.output_layer(last)
+    t = (t_emb, feats["2"], feats["6"], feats["20"], feats["23"])
+    s = student(x)
+    a = assistant(x)
+    crit = torch.nn.MSELoss()
+    s_loss = crit(s[0], t[0].detach())
+    a_loss = crit(t[1] - s[1], a[1]) + crit(t[2] - s[2], a[2]) + crit(t[3] - s[3], a[3]) + crit(t[4] - s[4], a[4]) \
+        + crit(t[0] - s[0], a[0])
+    gs_ref = grads_ref(s_loss, student, retain=True)
+    ga_ref = grads_ref(a_loss, assistant, retain=True)
+    (sl, al), gs, ga, _, s_m, a_m = R.kd_step_grads(t_sd, s_sd, a_sd, x, se=False)
+    close(sl, s_loss, "kd student loss", 1e-5); close(al, a_loss, "kd assistant loss", 1e-5)
+    compare_grads(gs_ref, gs, "kd student", st, "kd/student/", keep=("conv1.weight", "layer1.0.bn2.weight",
+                                                                    "layer4.2.conv2.weight", "fc.bias", "bn_o2.weight"))
+    compare_grads(ga_ref, ga, "kd assistant", st, "kd/assistant/", keep=("conv1.weight", "layer2.0.downsample.0.weight",
+                                                                        "layer3.5.bn1.bias", "fc.bias"))
+    st["kd/student_loss"] = np.float64(s_loss.item())
+    st["kd/assistant_loss"] = np.float64(a_loss.item())
+    pack(st, "kd/t_emb", t_emb); pack(st, "kd/s_emb", s[0]); pack(st, "kd/a_emb", a[0])
+    np.savez_compressed(os.path.join(OUT, "resnet_kd.npz"), **st)
+    print(f"[golden] resnet34 + kd ok ({time.time() - t0:.1f}s)")
+
+    # ------------------------------------------------------------------ losses (a14)
+    st = {}
+    a_ = torch.from_numpy(G.normal("loss/a", 2 * 3 * 16 * 16).reshape(2, 3, 16, 16).astype(np.float32))
+    b_ = torch.from_numpy(G.normal("loss/b", 2 * 3 * 16 * 16).reshape(2, 3, 16, 16).astype(np.float32))
+    lm = torch.from_numpy(G.normal("loss/lm", 2 * 97 * 8 * 8).reshape(2, 97, 8, 8).astype(np.float32)) * 0.1
+    lt = G.synth_heatmap(2, 8, 5, 1.3)
+    pl = torch.from_numpy(G.normal("loss/pl", 2 * 11 * 8 * 8).reshape(2, 11, 8, 8).astype(np.float32))
+    pt = G.synth_parsing(2, 8, 11)
+    for nm, ref_l, mine_l, args in (("mse97", loss_mod.MSELossFunc(), R.mse97, (a_, b_)),
+                                    ("landmark", loss_mod.MSELoss_Landmark(), R.landmark_loss, (lm, lt)),
+                                    ("nll2d", loss_mod.CrossEntropyLoss2d(), R.nll2d, (pl, pt))):
+        x0 = args[0].clone().requires_grad_(True)
+        lv = ref_l(x0, args[1])
+        g0, = torch.autograd.grad(lv, x0)
+        x1 = args[0].clone().requires_grad_(True)
+        lv1 = mine_l(x1, args[1])
+        g1, = torch.autograd.grad(lv1, x1)
+        close(lv1, lv, nm, 1e-6); close(g1, g0, nm + " grad", 1e-5)
+        st[nm + "/in"] = args[0].numpy(); st[nm + "/target"] = args[1].numpy()
+        st[nm + "/loss"] = np.float64(lv.item()); st[nm + "/grad"] = g0.numpy()
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), **st)
+
+    # ------------------------------------------------------------------ pair distance + ROC (a20)
+    spec = importlib.util.spec_from_file_location("ref_utils_utils", os.path.join(REF, "utils", "utils.py"))
+    uu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(uu)
+    from sklearn.model_selection import KFold
+    p = 600
+    e1, e2, same = G.synth_pairs(p, 512, seed=0)
+    e1 *= 1.0; e2 *= 1.0
+    thresholds = np.arange(0, 12000, 3)
+    np.random.seed(1234)
+    tpr, fpr, acc, best = uu.calculate_roc(thresholds, e1, e2, same, nrof_folds=10, pca=0)
+    np.random.seed(1234)
+    folds = list(KFold(n_splits=10, shuffle=True).split(np.arange(p)))
+    tpr2, fpr2, acc2, best2 = R.calculate_roc(thresholds, e1, e2, same, folds)
+    assert np.array_equal(tpr, tpr2) and np.array_equal(fpr, fpr2) and acc == acc2 and np.array_equal(best, best2), \
+        "ROC restatement differs from utils/utils.py:calculate_roc"
+    fold_id = np.empty(p, dtype=np.int64)
+    for f, (_, te) in enumerate(folds):
+        fold_id[te] = f
+    np.savez_compressed(os.path.join(OUT, "roc.npz"), tpr=tpr, fpr=fpr, acc=np.float64(acc), best=best,
+                        fold_id=fold_id, dist=uu.np.sum(np.square(e1 - e2), 1), p=np.int64(p))
+    print(f"[golden] losses + roc ok ({time.time() - t0:.1f}s)")
+
+    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print(f"[golden] wrote fixtures to {OUT} in {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()
