@@ -1,0 +1,618 @@
+// xr_conv.hip -- implicit-GEMM convolution family for gfx950 (CDNA4, wave64, MFMA 32x32x16 bf16).
+//
+// One gather engine serves Conv2d forward, Conv2d input-gradient, ConvTranspose2d forward/backward and
+// Linear (as a full-extent convolution):
+//   out[m][k] = sum_{tap,c} gather(in)[m][tap][c] * wpack[k][tap*C + c]        (xr_conv_igemm)
+//   dwp[k][tap*C + c] += sum_m dy[m][k] * gather(in)[m][tap][c]                (xr_conv_wgrad)
+// Activations are NHWC so a tap's C-slice is one contiguous, coalesced 16-B-chunk row; both operands are
+// staged through LDS in a K-contiguous XOR-swizzled image (conflict-free ds_read_b128 for the 32x32x16
+// operand map) -- for the weight gradient, where the reduction runs over pixels, the images stay
+// [pixel][channel] and the operands are fetched with the gfx950 transposing LDS read ds_read_b64_tr_b16.
+// XR_F32 mode keeps fp32 tensors in HBM and runs each product as hi*hi + hi*lo + lo*hi split-bf16 MFMAs.
+//
+// Replaces the ATen conv calls issued by /root/reference model/FSRnet.py:79,85,110,312,318,345,351,384,391,
+// 392,432,436,439; SUPER_RESOLUTION/model/model_irse.py:56-60,140,147; model/resnet.py:9-16,158,170.
+#include "xr_common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 64;        // reduction elements per LDS stage
+constexpr int NT = 256;       // threads per workgroup (4 waves)
+
+struct IgemmP {
+  const void* in;
+  const bf16_t* w_hi;
+  const bf16_t* w_lo;
+  const float* bias;
+  void* out;
+  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo, M, tiles_n;
+};
+
+// decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
+template <bool TR>
+__device__ __forceinline__ void decode_pixel(int m, int M, int HoWo, int Wo, int HW, int stride, int pad, bool& valid,
+                                             int& nb, int& oh0, int& ow0) {
+  valid = m < M;
+  int mm = valid ? m : 0;
+  int n = mm / HoWo;
+  int rem = mm - n * HoWo;
+  int ho = rem / Wo;
+  int wo = rem - ho * Wo;
+  nb = n * HW;
+  if (TR) {
+    oh0 = ho + pad;
+    ow0 = wo + pad;
+  } else {
+    oh0 = ho * stride - pad;
+    ow0 = wo * stride - pad;
+  }
+}
+
+// input coordinate for tap (r,s); returns validity and pixel offset hi*W+wi
+template <bool TR>
+__device__ __forceinline__ bool tap_coord(int oh0, int ow0, int r, int s, int stride, int H, int W, int& pix) {
+  int hi, wi;
+  if (TR) {
+    int th = oh0 - r, tw = ow0 - s;
+    if (th < 0 || tw < 0) return false;
+    if (stride == 1) {
+      hi = th; wi = tw;
+    } else {
+      hi = th / stride; wi = tw / stride;
+      if (hi * stride != th || wi * stride != tw) return false;
+    }
+  } else {
+    hi = oh0 + r; wi = ow0 + s;
+  }
+  if ((unsigned)hi >= (unsigned)H || (unsigned)wi >= (unsigned)W) return false;
+  pix = hi * W + wi;
+  return true;
+}
+
+// LDS operand image: rows of 64 bf16 (128 B), 16-B chunk index XOR-swizzled by (row>>1)&7
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16_t h0, l0, h1, l1;
+    split_bf(v[2 * i], h0, l0);
+    split_bf(v[2 * i + 1], h1, l1);
+    h[i] = (unsigned)h0 | ((unsigned)h1 << 16);
+    l[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ forward/dgrad
+template <int MODE, int BM, int BN, int WM, bool TR>
+__global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
+  constexpr int WN = 4 / WM;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int NS = MODE ? 2 : 1;
+  constexpr int RA = BM / 32, RB = BN / 32;
+  using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
+  using out_t = in_t;
+  constexpr int PADE = 16 / sizeof(out_t);
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + NS * BM * 128;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int tile_n = blockIdx.x % p.tiles_n;
+  const int tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+  const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
+
+  const int cc = t & 7;   // 16-B chunk column inside the K-stage
+  const int rbase = t >> 3;
+  bool a_valid[RA];
+  int a_nb[RA], a_oh[RA], a_ow[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i)
+    decode_pixel<TR>(m0 + rbase + 32 * i, p.M, HoWo, p.Wo, HW, p.stride, p.pad, a_valid[i], a_nb[i], a_oh[i], a_ow[i]);
+
+  float a_f[MODE ? RA : 1][8];
+  uint4 a_u[MODE ? 1 : RA];
+  uint4 b_hi[RB], b_lo[MODE ? RB : 1];
+  const int taps = p.R * p.S;
+
+  auto load_stage = [&](int kk) {
+    const int k0 = kk * BK + cc * 8;
+    const int tap = k0 / p.C;
+    const int c = k0 - tap * p.C;
+    const int r = tap / p.S;
+    const int s = tap - r * p.S;
+    const bool tap_ok = tap < taps;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int pix = 0;
+      bool ok = a_valid[i] && tap_ok && tap_coord<TR>(a_oh[i], a_ow[i], r, s, p.stride, p.H, p.W, pix);
+      const in_t* src = in + ((size_t)(a_nb[i] + pix) * p.C + c);
+      if constexpr (MODE == 1) {
+        if (ok) {
+          ld8(src, a_f[i]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a_f[i][e] = 0.f;
+        }
+      } else {
+        a_u[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = n0 + rbase + 32 * i;
+      const bool ok = row < p.K;
+      const size_t off = (size_t)row * p.Kg + k0;
+      b_hi[i] = ok ? *reinterpret_cast<const uint4*>(p.w_hi + off) : make_uint4(0, 0, 0, 0);
+      if constexpr (MODE == 1) b_lo[i] = ok ? *reinterpret_cast<const uint4*>(p.w_lo + off) : make_uint4(0, 0, 0, 0);
+    }
+  };
+
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int off = lds_off(rbase + 32 * i, cc);
+      if constexpr (MODE == 1) {
+        uint4 hi, lo;
+        split8(a_f[i], hi, lo);
+        *reinterpret_cast<uint4*>(sA + off) = hi;
+        *reinterpret_cast<uint4*>(sA + BM * 128 + off) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(sA + off) = a_u[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int off = lds_off(rbase + 32 * i, cc);
+      *reinterpret_cast<uint4*>(sB + off) = b_hi[i];
+      if constexpr (MODE == 1) *reinterpret_cast<uint4*>(sB + BN * 128 + off) = b_lo[i];
+    }
+  };
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nk = p.Kg / BK;
+
+  load_stage(0);
+  for (int kk = 0; kk < nk; ++kk) {
+    store_stage();
+    __syncthreads();
+    if (kk + 1 < nk) load_stage(kk + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t fa[TM][NS], fb[TN][NS];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int off = lds_off(wm0 + i * 32 + lr, ks * 2 + lh);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fa[i][s] = *reinterpret_cast<const bf16x8_t*>(sA + s * BM * 128 + off);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int off = lds_off(wn0 + j * 32 + lr, ks * 2 + lh);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fb[j][s] = *reinterpret_cast<const bf16x8_t*>(sB + s * BN * 128 + off);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (MODE == 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: accumulators (+bias) -> LDS row image -> coalesced 16-B-chunk stores
+  out_t* stage = reinterpret_cast<out_t*>(smem);
+  constexpr int PITCH = BN + PADE;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn0 + j * 32 + lr;
+      const float bv = (p.bias != nullptr && n0 + col < p.K) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        XrT<out_t>::st(stage + row * PITCH + col, acc[i][j][e] + bv);
+      }
+    }
+  __syncthreads();
+  out_t* __restrict__ out = reinterpret_cast<out_t*>(p.out);
+  constexpr int CPR = BN / 8;  // chunks per tile row
+  for (int idx = t; idx < BM * CPR; idx += NT) {
+    const int row = idx / CPR, ch = idx - row * CPR;
+    const int m = m0 + row;
+    const int ncol = n0 + ch * 8;
+    if (m >= p.M || ncol >= p.ldo) continue;
+    const out_t* sp = stage + row * PITCH + ch * 8;
+    out_t* dp = out + (size_t)m * p.ldo + ncol;
+    if (ncol + 8 <= p.ldo) {
+      if constexpr (sizeof(out_t) == 2) {
+        *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+      } else {
+        *reinterpret_cast<float4*>(dp) = *reinterpret_cast<const float4*>(sp);
+        *reinterpret_cast<float4*>(dp + 4) = *reinterpret_cast<const float4*>(sp + 4);
+      }
+    } else {
+      for (int e = 0; e < 8 && ncol + e < p.ldo; ++e) dp[e] = sp[e];
+    }
+  }
+}
+
+template <int MODE, int BM, int BN>
+constexpr size_t igemm_smem() {
+  constexpr int NS = MODE ? 2 : 1;
+  constexpr size_t ops = (size_t)NS * (BM + BN) * 128;
+  constexpr size_t esz = MODE ? 4 : 2;
+  constexpr size_t stg = (size_t)BM * (BN + 16 / esz) * esz;
+  return ops > stg ? ops : stg;
+}
+
+template <int MODE, int BM, int BN, int WM, bool TR>
+int launch_igemm(IgemmP& p, hipStream_t st) {
+  p.tiles_n = cdiv(p.ldo < p.K ? p.K : (p.K + 7) / 8 * 8, BN);
+  const int tiles_m = cdiv(p.M, BM);
+  constexpr size_t smem = igemm_smem<MODE, BM, BN>();
+  auto kern = igemm_kernel<MODE, BM, BN, WM, TR>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    if (e != hipSuccess) {
+      xr_set_error("xr_conv_igemm: hipFuncSetAttribute(%zu) failed: %s", smem, hipGetErrorString(e));
+      return XR_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT), smem, st, p);
+  XR_CHECK_LAUNCH("xr_conv_igemm");
+  return XR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgradP {
+  const void* in;
+  const void* dy;
+  float* dwp;
+  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c;
+};
+
+// transposing fragment fetch from a [pixel][col] LDS image (pitch bytes): 8 pixels x 1 column per lane
+__device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int pitch, int pix0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int q = i >> 2, pp = i & 3;
+  const int cgrp = g & 1, h = g >> 1;
+  const int byte = (pix0 + 8 * h + q) * pitch + (col0 + 16 * cgrp + 4 * pp) * 2;
+  typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(img + byte));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(img + byte + 4 * pitch));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int MODE, int BR, int BC, bool TR>
+__global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
+  constexpr int BP = 64;  // pixels per stage
+  constexpr int NS = MODE ? 2 : 1;
+  constexpr int WC = BC / 64, WR = BR / 64;  // wave grid (wave tile 64x64)
+  static_assert(WC * WR == 4, "4 waves");
+  constexpr int PY = BR * 2 + 64, PX = BC * 2 + 64;  // image pitches: == 64 (mod 256) -> conflict-free tr reads
+  constexpr int CRY = BR / 8, CRX = BC / 8;          // chunks per image row
+  constexpr int NY = BP * CRY / NT, NX = BP * CRX / NT;
+  using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sY = smem;
+  unsigned char* sX = smem + NS * BP * PY;
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int tile_c = blockIdx.x % p.tiles_c, tile_r = blockIdx.x / p.tiles_c;
+  const int r0 = tile_r * BR, c0 = tile_c * BC;
+  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+  const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
+  const in_t* __restrict__ dy = reinterpret_cast<const in_t*>(p.dy);
+
+  // X-gather column decode: fixed per thread for the whole kernel
+  const int xch = t % CRX, xrow0 = t / CRX;
+  const int j0 = c0 + xch * 8;
+  const int tap = j0 / p.C;
+  const int cch = j0 - tap * p.C;
+  const int tr_ = tap / p.S, ts_ = tap - tr_ * p.S;
+  const bool col_ok = (tap < p.R * p.S) && (j0 < p.Kg);
+  const int ych = t % CRY, yrow0 = t / CRY;
+  const bool ycol_ok = (r0 + ych * 8) < p.ldy;
+
+  float y_f[MODE ? NY : 1][8], x_f[MODE ? NX : 1][8];
+  uint4 y_u[MODE ? 1 : NY], x_u[MODE ? 1 : NX];
+
+  auto load_stage = [&](int step) {
+    const int mbase = step * BP;
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int m = mbase + yrow0 + (NT / CRY) * i;
+      const bool ok = ycol_ok && m < p.M;
+      const in_t* src = dy + ((size_t)m * p.ldy + r0 + ych * 8);
+      if constexpr (MODE == 1) {
+        if (ok) ld8(src, y_f[i]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y_f[i][e] = 0.f;
+        }
+      } else {
+        y_u[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int m = mbase + xrow0 + (NT / CRX) * i;
+      bool valid; int nb, oh0, ow0, pix = 0;
+      decode_pixel<TR>(m, p.M, HoWo, p.Wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
+      const bool ok = valid && col_ok && tap_coord<TR>(oh0, ow0, tr_, ts_, p.stride, p.H, p.W, pix);
+      const in_t* src = in + ((size_t)(nb + pix) * p.C + cch);
+      if constexpr (MODE == 1) {
+        if (ok) ld8(src, x_f[i]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x_f[i][e] = 0.f;
+        }
+      } else {
+        x_u[i] = ok ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int off = (yrow0 + (NT / CRY) * i) * PY + ych * 16;
+      if constexpr (MODE == 1) {
+        uint4 hi, lo;
+        split8(y_f[i], hi, lo);
+        *reinterpret_cast<uint4*>(sY + off) = hi;
+        *reinterpret_cast<uint4*>(sY + BP * PY + off) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(sY + off) = y_u[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int off = (xrow0 + (NT / CRX) * i) * PX + xch * 16;
+      if constexpr (MODE == 1) {
+        uint4 hi, lo;
+        split8(x_f[i], hi, lo);
+        *reinterpret_cast<uint4*>(sX + off) = hi;
+        *reinterpret_cast<uint4*>(sX + BP * PX + off) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(sX + off) = x_u[i];
+      }
+    }
+  };
+
+  f32x16_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int wr0 = (wave / WC) * 64, wc0 = (wave % WC) * 64;
+  const int s_begin = blockIdx.y * p.steps_per_split;
+  int s_end = s_begin + p.steps_per_split;
+  if (s_end > p.steps_total) s_end = p.steps_total;
+
+  if (s_begin < s_end) {
+    load_stage(s_begin);
+    for (int step = s_begin; step < s_end; ++step) {
+      store_stage();
+      __syncthreads();
+      if (step + 1 < s_end) load_stage(step + 1);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8_t fa[2][NS], fb[2][NS];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) fa[i][s] = tr_frag(sY + s * BP * PY, PY, ks * 16, wr0 + i * 32, lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int s = 0; s < NS; ++s) fb[j][s] = tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (MODE == 1) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = c0 + wc0 + j * 32 + lr;
+      if (col >= p.Kg) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = r0 + wr0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row < p.K) atomicAdd(p.dwp + (size_t)row * p.Kg + col, acc[i][j][e]);
+      }
+    }
+}
+
+template <int MODE, int BR, int BC, bool TR>
+int launch_wgrad(WgradP& p, int split, hipStream_t st) {
+  constexpr int NS = MODE ? 2 : 1;
+  constexpr size_t smem = (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64));
+  p.tiles_c = cdiv(p.Kg, BC);
+  const int tiles_r = cdiv(p.K, BR);
+  p.steps_total = cdiv(p.M, 64);
+  if (split < 1) split = 1;
+  if (split > p.steps_total) split = p.steps_total;
+  p.steps_per_split = cdiv(p.steps_total, split);
+  split = cdiv(p.steps_total, p.steps_per_split);
+  auto kern = wgrad_kernel<MODE, BR, BC, TR>;
+  if (smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    if (e != hipSuccess) {
+      xr_set_error("xr_conv_wgrad: hipFuncSetAttribute(%zu) failed: %s", smem, hipGetErrorString(e));
+      return XR_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_c * tiles_r), (unsigned)split), dim3(NT), smem, st, p);
+  XR_CHECK_LAUNCH("xr_conv_wgrad");
+  return XR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pack / unpack
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int A2,
+                                   int taps, int B, int Bp, int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb,
+                                   int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = i / Kg;
+    const int j = (int)(i - a * Kg);
+    const int tp = j / Bp, b = j - tp * Bp;
+    float v = 0.f;
+    if (tp < taps && b < B) {
+      const int64_t a1 = a / A2, a2 = a - a1 * A2;
+      v = src[a1 * sa1 + a2 * sa2 + tp * st_ + b * sb];
+    }
+    if (lo != nullptr) {
+      bf16_t h, l;
+      split_bf(v, h, l);
+      hi[i] = h;
+      lo[i] = l;
+    } else {
+      hi[i] = f2bf(v);
+    }
+  }
+}
+
+__global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ dst, int A2, int taps, int B,
+                                    int Bp, int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate,
+                                    int64_t total) {
+  // iterate over destination-meaningful elements (a, tap, b)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % B);
+    const int64_t r = i / B;
+    const int tp = (int)(r % taps);
+    const int64_t a = r / taps;
+    const int64_t a1 = a / A2, a2 = a - a1 * A2;
+    const float v = packed[a * Kg + (int64_t)tp * Bp + b];
+    float* d = dst + a1 * sa1 + a2 * sa2 + tp * st_ + b * sb;
+    *d = accumulate ? (*d + v) : v;
+  }
+}
+
+}  // namespace
+
+extern "C" int xr_pack_weight(const float* src, void* dst_hi, void* dst_lo, int A1, int A2, int taps, int B, int Bp,
+                              int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, void* stream) {
+  XR_CHECK_ARG(src && dst_hi, "xr_pack_weight: null pointer");
+  XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Bp % 8 == 0 && Kg % 64 == 0 && Kg >= taps * Bp,
+               "xr_pack_weight: bad dims A1=%d A2=%d taps=%d B=%d Bp=%d Kg=%d", A1, A2, taps, B, Bp, Kg);
+  const int64_t total = (int64_t)A1 * A2 * Kg;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst_hi,
+                     (bf16_t*)dst_lo, A2, taps, B, Bp, Kg, sa1, sa2, st_, sb, total);
+  XR_CHECK_LAUNCH("xr_pack_weight");
+  return XR_OK;
+}
+
+extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,
+                               int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate, void* stream) {
+  XR_CHECK_ARG(packed && dst, "xr_unpack_wgrad: null pointer");
+  XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Kg >= taps * Bp, "xr_unpack_wgrad: bad dims");
+  const int64_t total = (int64_t)A1 * A2 * taps * B;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, dst, A2, taps, B, Bp,
+                     Kg, sa1, sa2, st_, sb, accumulate, total);
+  XR_CHECK_LAUNCH("xr_unpack_wgrad");
+  return XR_OK;
+}
+
+extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w_hi, const void* w_lo, const float* bias, void* out,
+                             int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
+                             int transposed, int Kg, int ldo, void* stream) {
+  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
+  XR_CHECK_ARG(in && w_hi && out, "xr_conv_igemm: null pointer");
+  XR_CHECK_ARG(dtype == XR_BF16 || w_lo, "xr_conv_igemm: XR_F32 needs the lo weight plane");
+  XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
+               "xr_conv_igemm: non-positive dimension");
+  XR_CHECK_ARG(C % 8 == 0, "xr_conv_igemm: C=%d must be a multiple of 8 (pad channels)", C);
+  XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_igemm: Kg=%d must be a multiple of 64 and >= R*S*C=%d", Kg,
+               R * S * C);
+  XR_CHECK_ARG(ldo >= K && ldo % 8 == 0, "xr_conv_igemm: ldo=%d must be >= K=%d and a multiple of 8", ldo, K);
+  XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31) && (long long)N * H * W * C < (1ll << 40), "xr_conv_igemm: too large");
+  if (!transposed) {
+    XR_CHECK_ARG((H + 2 * pad - R) / stride + 1 == Ho && (W + 2 * pad - S) / stride + 1 == Wo,
+                 "xr_conv_igemm: output %dx%d inconsistent with input %dx%d k%d s%d p%d", Ho, Wo, H, W, R, stride, pad);
+  } else {
+    XR_CHECK_ARG((Ho + 2 * pad - R) / stride + 1 == H && (Wo + 2 * pad - S) / stride + 1 == W,
+                 "xr_conv_igemm(transposed): output %dx%d inconsistent with input %dx%d k%d s%d p%d", Ho, Wo, H, W, R,
+                 stride, pad);
+  }
+  IgemmP p{in, (const bf16_t*)w_hi, (const bf16_t*)w_lo, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
+           N * Ho * Wo, 0};
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = K > 64;
+  if (dtype == XR_BF16) {
+    if (wide) return transposed ? launch_igemm<0, 128, 128, 2, true>(p, st) : launch_igemm<0, 128, 128, 2, false>(p, st);
+    return transposed ? launch_igemm<0, 128, 64, 4, true>(p, st) : launch_igemm<0, 128, 64, 4, false>(p, st);
+  }
+  if (wide) return transposed ? launch_igemm<1, 128, 128, 2, true>(p, st) : launch_igemm<1, 128, 128, 2, false>(p, st);
+  return transposed ? launch_igemm<1, 128, 64, 4, true>(p, st) : launch_igemm<1, 128, 64, 4, false>(p, st);
+}
+
+extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,
+                             int Wo, int K, int R, int S, int stride, int pad, int transposed, int ldy, int Kg, int split,
+                             void* stream) {
+  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_wgrad: bad dtype %d", dtype);
+  XR_CHECK_ARG(in && dy && dwp, "xr_conv_wgrad: null pointer");
+  XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
+               "xr_conv_wgrad: non-positive dimension");
+  XR_CHECK_ARG(C % 8 == 0 && ldy % 8 == 0 && ldy >= K, "xr_conv_wgrad: C=%d / ldy=%d must be multiples of 8, ldy >= K", C,
+               ldy);
+  XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_wgrad: bad Kg=%d", Kg);
+  XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
+  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0};
+  hipStream_t st = (hipStream_t)stream;
+  const bool tall = K > 64;
+  if (dtype == XR_BF16) {
+    if (tall) return transposed ? launch_wgrad<0, 128, 128, true>(p, split, st) : launch_wgrad<0, 128, 128, false>(p, split, st);
+    return transposed ? launch_wgrad<0, 64, 256, true>(p, split, st) : launch_wgrad<0, 64, 256, false>(p, split, st);
+  }
+  if (tall) return transposed ? launch_wgrad<1, 128, 128, true>(p, split, st) : launch_wgrad<1, 128, 128, false>(p, split, st);
+  return transposed ? launch_wgrad<1, 64, 256, true>(p, split, st) : launch_wgrad<1, 64, 256, false>(p, split, st);
+}

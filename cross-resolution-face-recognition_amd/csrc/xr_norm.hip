@@ -1,0 +1,511 @@
+// xr_norm.hip -- normalisation / activation / SE family on NHWC tensors viewed as [G][rows][C].
+//
+// HBM-bound kernels: every thread owns one fixed 8-channel chunk (16 B of bf16 / 32 B of fp32) so the
+// per-channel coefficients live in registers, rows are walked with fully coalesced 16-B-per-lane accesses,
+// and the per-(group,channel) reductions are done register -> LDS -> one atomic per block.
+//
+// Replaces aten::batch_norm / instance_norm / prelu / relu / add / adaptive_avg_pool2d / sigmoid / mul call
+// sites: /root/reference model/FSRnet.py:81-98,112-135,319,347,385,434; SUPER_RESOLUTION/model/model_irse.py:
+// 23-46,56-66,76-91,141-148; model/resnet.py:24-47,159,167,173.
+#include "xr_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct Geo {
+  int G, rows, C, cpr, rpb, active, rows_per_block;
+};
+
+static Geo make_geo(int G, int rows, int C, int target_blocks) {
+  Geo g;
+  g.G = G; g.rows = rows; g.C = C;
+  g.cpr = C / 8;
+  g.rpb = NT / g.cpr;
+  g.active = g.rpb * g.cpr;
+  int nb = target_blocks / (G > 0 ? G : 1);
+  if (nb < 1) nb = 1;
+  int rpbk = cdiv(rows, nb);
+  rpbk = cdiv(rpbk, g.rpb) * g.rpb;
+  if (rpbk < g.rpb) rpbk = g.rpb;
+  g.rows_per_block = rpbk;
+  return g;
+}
+static dim3 geo_grid(const Geo& g) { return dim3((unsigned)cdiv(g.rows, g.rows_per_block), (unsigned)g.G); }
+
+__device__ __forceinline__ float act_fwd(float z, float a, int act) {
+  if (act == XR_ACT_PRELU) return z > 0.f ? z : a * z;
+  if (act == XR_ACT_RELU) return z > 0.f ? z : 0.f;
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, float a, int act) {
+  if (act == XR_ACT_PRELU) return z > 0.f ? 1.f : a;
+  if (act == XR_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ void load_coef8(const float* p, int idx, float (&v)[8], float dflt) {
+  if (p != nullptr) {
+    ld8(p + idx, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = dflt;
+  }
+}
+
+// block-level reduction of NV per-thread 8-vectors over the rpb row-lanes, then atomics to dst[v][g][c]
+template <int NV>
+__device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV][8], float* dst, int G, int g, int C, int cch, int rsub,
+                                                    int rpb, bool active, float* lds) {
+  // lds: [rpb][C] floats per vector, processed one vector at a time
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) lds[rsub * C + cch * 8 + e] = acc[v][e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+      float s = 0.f;
+      for (int r = 0; r < rpb; ++r) s += lds[r * C + c];
+      atomicAdd(dst + ((size_t)v * G + g) * C + c, s);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, Geo geo) {
+  extern __shared__ float lds[];
+  const int t = threadIdx.x;
+  const bool active = t < geo.active;
+  const int cch = t % geo.cpr, rsub = t / geo.cpr;
+  const int g = blockIdx.y;
+  const int r_begin = blockIdx.x * geo.rows_per_block;
+  int r_end = r_begin + geo.rows_per_block;
+  if (r_end > geo.rows) r_end = geo.rows;
+  float acc[2][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = 0.f;
+  if (active) {
+    const T* base = x + ((size_t)g * geo.rows) * geo.C + cch * 8;
+    for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+      float v[8];
+      ld8(base + (size_t)r * geo.C, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        acc[0][e] += v[e];
+        acc[1][e] += v[e] * v[e];
+      }
+    }
+  }
+  block_reduce_atomic<2>(acc, sums, geo.G, g, geo.C, cch, rsub, geo.rpb, active, lds);
+}
+
+__global__ void norm_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
+                                     float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ rmean,
+                                     float* __restrict__ rvar, int G, int rows, int C, float eps, float momentum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * C) return;
+  const int c = i % C;
+  const float n = (float)rows;
+  const float mu = sums[i] / n;
+  float var = sums[(size_t)G * C + i] / n - mu * mu;
+  var = var > 0.f ? var : 0.f;
+  const float is = rsqrtf(var + eps);
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  if (mean) mean[i] = mu;
+  if (invstd) invstd[i] = is;
+  scale[i] = ga * is;
+  shift[i] = be - mu * ga * is;
+  if (rmean != nullptr && G == 1) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+    const float unb = rows > 1 ? var * n / (n - 1.f) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                                      float* scale, float* shift, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = rsqrtf(rvar[c] + eps);
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  scale[c] = ga * is;
+  shift[c] = be - rmean[c] * ga * is;
+}
+
+struct AffP {
+  const void* x; const float* scale; const float* shift; const void* res; const float* alpha; int act;
+  void* y; const void* dy; float* red; const float* coef; void* dx; void* dres;
+  int coef_per_group;  // scale/shift are [G][C] (1) or [C] (0)
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void affine_act_kernel(AffP p, Geo geo) {
+  const int t = threadIdx.x;
+  if (t >= geo.active) return;
+  const int cch = t % geo.cpr, rsub = t / geo.cpr;
+  const int g = blockIdx.y;
+  const int r_begin = blockIdx.x * geo.rows_per_block;
+  int r_end = r_begin + geo.rows_per_block;
+  if (r_end > geo.rows) r_end = geo.rows;
+  const int ci = (p.coef_per_group ? g * geo.C : 0) + cch * 8;
+  float sc[8], sh[8], al[8];
+  load_coef8(p.scale, ci, sc, 1.f);
+  load_coef8(p.shift, ci, sh, 0.f);
+  load_coef8(p.alpha, cch * 8, al, 0.f);
+  const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
+  const T* x = reinterpret_cast<const T*>(p.x) + gbase;
+  const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
+  T* y = reinterpret_cast<T*>(p.y) + gbase;
+  for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+    float v[8], rv[8], o[8];
+    ld8(x + (size_t)r * geo.C, v);
+    if (res) ld8(res + (size_t)r * geo.C, rv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float z = v[e] * sc[e] + sh[e];
+      if (res) z += rv[e];
+      o[e] = act_fwd(z, al[e], p.act);
+    }
+    st8(y + (size_t)r * geo.C, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void affine_act_bwd_reduce_kernel(AffP p, Geo geo) {
+  extern __shared__ float lds[];
+  const int t = threadIdx.x;
+  const bool active = t < geo.active;
+  const int cch = t % geo.cpr, rsub = t / geo.cpr;
+  const int g = blockIdx.y;
+  const int r_begin = blockIdx.x * geo.rows_per_block;
+  int r_end = r_begin + geo.rows_per_block;
+  if (r_end > geo.rows) r_end = geo.rows;
+  float acc[3][8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
+  if (active) {
+    const int ci = (p.coef_per_group ? g * geo.C : 0) + cch * 8;
+    float sc[8], sh[8], al[8];
+    load_coef8(p.scale, ci, sc, 1.f);
+    load_coef8(p.shift, ci, sh, 0.f);
+    load_coef8(p.alpha, cch * 8, al, 0.f);
+    const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
+    const T* x = reinterpret_cast<const T*>(p.x) + gbase;
+    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
+    const T* dy = reinterpret_cast<const T*>(p.dy) + gbase;
+    for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+      float v[8], rv[8], d[8];
+      ld8(x + (size_t)r * geo.C, v);
+      ld8(dy + (size_t)r * geo.C, d);
+      if (res) ld8(res + (size_t)r * geo.C, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = v[e] * sc[e] + sh[e];
+        if (res) z += rv[e];
+        const float dz = d[e] * act_grad(z, al[e], p.act);
+        acc[0][e] += dz;
+        acc[1][e] += dz * v[e];
+        if (p.act == XR_ACT_PRELU && z <= 0.f) acc[2][e] += d[e] * z;
+      }
+    }
+  }
+  block_reduce_atomic<3>(acc, p.red, geo.G, g, geo.C, cch, rsub, geo.rpb, active, lds);
+}
+
+__global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       float* __restrict__ coef, float* dgamma, float* dbeta, float* dalpha, int G, int rows,
+                                       int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float n = (float)rows;
+  const float ga = gamma ? gamma[c] : 1.f;
+  float dg = 0.f, db = 0.f, da = 0.f;
+  const size_t GC = (size_t)G * C;
+  for (int g = 0; g < G; ++g) {
+    const size_t i = (size_t)g * C + c;
+    const float s_dz = red[i], s_dzx = red[GC + i];
+    const float mu = mean[i], is = invstd[i];
+    const float s_dzxhat = is * (s_dzx - mu * s_dz);
+    const float m1 = s_dz / n, m2 = s_dzxhat / n;
+    const float A = ga * is;
+    const float B = -ga * is * is * m2;
+    coef[i] = A;
+    coef[GC + i] = B;
+    coef[2 * GC + i] = -A * m1 - B * mu;
+    dg += s_dzxhat;
+    db += s_dz;
+    da += red[2 * GC + i];
+  }
+  if (dgamma) dgamma[c] += dg;
+  if (dbeta) dbeta[c] += db;
+  if (dalpha) dalpha[c] += da;
+}
+
+// sums red[v][g][c] over g into out[c] (used for PReLU-only dalpha and bias gradients)
+__global__ void reduce_groups_kernel(const float* __restrict__ red, float* __restrict__ out, int G, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int g = 0; g < G; ++g) s += red[(size_t)g * C + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void affine_act_bwd_apply_kernel(AffP p, Geo geo) {
+  const int t = threadIdx.x;
+  if (t >= geo.active) return;
+  const int cch = t % geo.cpr, rsub = t / geo.cpr;
+  const int g = blockIdx.y;
+  const int r_begin = blockIdx.x * geo.rows_per_block;
+  int r_end = r_begin + geo.rows_per_block;
+  if (r_end > geo.rows) r_end = geo.rows;
+  const int ci = (p.coef_per_group ? g * geo.C : 0) + cch * 8;
+  float sc[8], sh[8], al[8], cA[8], cB[8], cC[8];
+  load_coef8(p.scale, ci, sc, 1.f);
+  load_coef8(p.shift, ci, sh, 0.f);
+  load_coef8(p.alpha, cch * 8, al, 0.f);
+  const size_t GC = (size_t)geo.G * geo.C;
+  if (p.coef) {
+    ld8(p.coef + (size_t)g * geo.C + cch * 8, cA);
+    ld8(p.coef + GC + (size_t)g * geo.C + cch * 8, cB);
+    ld8(p.coef + 2 * GC + (size_t)g * geo.C + cch * 8, cC);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { cA[e] = sc[e]; cB[e] = 0.f; cC[e] = 0.f; }
+  }
+  const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
+  const T* x = reinterpret_cast<const T*>(p.x) + gbase;
+  const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
+  const T* dy = reinterpret_cast<const T*>(p.dy) + gbase;
+  T* dx = p.dx ? reinterpret_cast<T*>(p.dx) + gbase : nullptr;
+  T* dres = p.dres ? reinterpret_cast<T*>(p.dres) + gbase : nullptr;
+  for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+    float v[8], rv[8], d[8], o[8], dzv[8];
+    ld8(x + (size_t)r * geo.C, v);
+    ld8(dy + (size_t)r * geo.C, d);
+    if (res) ld8(res + (size_t)r * geo.C, rv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float z = v[e] * sc[e] + sh[e];
+      if (res) z += rv[e];
+      const float dz = d[e] * act_grad(z, al[e], p.act);
+      dzv[e] = dz;
+      o[e] = cA[e] * dz + cB[e] * v[e] + cC[e];
+    }
+    if (dx) st8(dx + (size_t)r * geo.C, o);
+    if (dres) st8(dres + (size_t)r * geo.C, dzv);
+  }
+}
+
+// --------------------------------------------------------------------------------------------- SE excitation
+__global__ __launch_bounds__(NT) void se_excite_fwd_kernel(const float* __restrict__ pooled_sum, const float* __restrict__ w1,
+                                                           const float* __restrict__ w2, float* __restrict__ hidden,
+                                                           float* __restrict__ s, int C, int Cr, float inv_hw) {
+  extern __shared__ float lds[];  // pooled[C] + hid[Cr]
+  float* pooled = lds;
+  float* hid = lds + C;
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int c = t; c < C; c += NT) pooled[c] = pooled_sum[(size_t)n * C + c] * inv_hw;
+  __syncthreads();
+  for (int j = wave; j < Cr; j += NT / 64) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += w1[(size_t)j * C + c] * pooled[c];
+    a = wave_sum(a);
+    if (lane == 0) {
+      a = a > 0.f ? a : 0.f;
+      hid[j] = a;
+      hidden[(size_t)n * Cr + j] = a;
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += NT) {
+    float a = 0.f;
+    for (int j = 0; j < Cr; ++j) a += w2[(size_t)c * Cr + j] * hid[j];
+    s[(size_t)n * C + c] = 1.f / (1.f + __expf(-a));
+  }
+}
+
+__global__ __launch_bounds__(NT) void se_excite_bwd_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                           const float* __restrict__ hidden, const float* __restrict__ s,
+                                                           const float* __restrict__ ds, float* __restrict__ dpre2,
+                                                           float* __restrict__ dhid, float* __restrict__ dpooled, int C,
+                                                           int Cr, float inv_hw) {
+  extern __shared__ float lds[];  // d2[C] + dh[Cr]
+  float* d2 = lds;
+  float* dh = lds + C;
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int c = t; c < C; c += NT) {
+    const float sv = s[(size_t)n * C + c];
+    const float v = ds[(size_t)n * C + c] * sv * (1.f - sv);
+    d2[c] = v;
+    dpre2[(size_t)n * C + c] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < Cr; j += NT / 64) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a += w2[(size_t)c * Cr + j] * d2[c];
+    a = wave_sum(a);
+    if (lane == 0) {
+      a = hidden[(size_t)n * Cr + j] > 0.f ? a : 0.f;
+      dh[j] = a;
+      dhid[(size_t)n * Cr + j] = a;
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += NT) {
+    float a = 0.f;
+    for (int j = 0; j < Cr; ++j) a += w1[(size_t)j * C + c] * dh[j];
+    dpooled[(size_t)n * C + c] = a * inv_hw;
+  }
+}
+
+// out[i][j] (+)= scale * sum_n A[n][i] * B[n][j]   (tiny outer-product accumulation; I*J threads)
+__global__ void small_atb_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out, int N,
+                                 int I, int J, float scale, int accumulate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= I * J) return;
+  const int i = idx / J, j = idx - i * J;
+  float a = 0.f;
+  for (int n = 0; n < N; ++n) a += A[(size_t)n * I + i] * B[(size_t)n * J + j];
+  a *= scale;
+  out[idx] = accumulate ? out[idx] + a : a;
+}
+
+template <typename T>
+static int launch_aff(void (*kern)(AffP, Geo), AffP& p, const Geo& geo, size_t smem, hipStream_t st, const char* name) {
+  hipLaunchKernelGGL(kern, geo_grid(geo), dim3(NT), smem, st, p, geo);
+  XR_CHECK_LAUNCH(name);
+  return XR_OK;
+}
+
+static int check_geo(const char* name, int dtype, int G, int rows, int C) {
+  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "%s: bad dtype %d", name, dtype);
+  XR_CHECK_ARG(G > 0 && rows > 0 && C > 0 && C % 8 == 0 && C <= 2048, "%s: bad geometry G=%d rows=%d C=%d", name, G, rows, C);
+  XR_CHECK_ARG(G <= 65535, "%s: G=%d too large", name, G);
+  return XR_OK;
+}
+
+}  // namespace
+
+extern "C" int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C, void* stream) {
+  if (int e = check_geo("xr_group_stats", dtype, G, rows, C)) return e;
+  XR_CHECK_ARG(x && sums, "xr_group_stats: null pointer");
+  Geo geo = make_geo(G, rows, C, 2048);
+  const size_t smem = (size_t)geo.rpb * C * sizeof(float);
+  if (dtype == XR_BF16)
+    hipLaunchKernelGGL(group_stats_kernel<bf16_t>, geo_grid(geo), dim3(NT), smem, (hipStream_t)stream, (const bf16_t*)x, sums, geo);
+  else
+    hipLaunchKernelGGL(group_stats_kernel<float>, geo_grid(geo), dim3(NT), smem, (hipStream_t)stream, (const float*)x, sums, geo);
+  XR_CHECK_LAUNCH("xr_group_stats");
+  return XR_OK;
+}
+
+extern "C" int xr_norm_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* invstd,
+                                float* scale, float* shift, float* running_mean, float* running_var, int G, int rows, int C,
+                                float eps, float momentum, void* stream) {
+  XR_CHECK_ARG(sums && scale && shift, "xr_norm_finalize: null pointer");
+  XR_CHECK_ARG(G > 0 && rows > 0 && C > 0, "xr_norm_finalize: bad geometry");
+  XR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "xr_norm_finalize: running stats must come in pairs");
+  XR_CHECK_ARG(running_mean == nullptr || G == 1, "xr_norm_finalize: running statistics need G == 1");
+  const int n = G * C;
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, mean,
+                     invstd, scale, shift, running_mean, running_var, G, rows, C, eps, momentum);
+  XR_CHECK_LAUNCH("xr_norm_finalize");
+  return XR_OK;
+}
+
+extern "C" int xr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                 float* scale, float* shift, int C, float eps, void* stream) {
+  XR_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "xr_bn_eval_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                     running_var, scale, shift, C, eps);
+  XR_CHECK_LAUNCH("xr_bn_eval_coeffs");
+  return XR_OK;
+}
+
+extern "C" int xr_affine_act(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                             const float* alpha, int act, void* y, int G, int rows, int C, int coef_per_group, void* stream) {
+  if (int e = check_geo("xr_affine_act", dtype, G, rows, C)) return e;
+  XR_CHECK_ARG(x && y, "xr_affine_act: null pointer");
+  XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act: PReLU needs alpha");
+  AffP p{x, scale, shift, res, alpha, act, y, nullptr, nullptr, nullptr, nullptr, nullptr, coef_per_group};
+  Geo geo = make_geo(G, rows, C, 4096);
+  if (dtype == XR_BF16) return launch_aff<bf16_t>(affine_act_kernel<bf16_t>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
+  return launch_aff<float>(affine_act_kernel<float>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
+}
+
+extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                        const float* alpha, int act, const void* dy, float* red, int G, int rows, int C,
+                                        int coef_per_group, void* stream) {
+  if (int e = check_geo("xr_affine_act_bwd_reduce", dtype, G, rows, C)) return e;
+  XR_CHECK_ARG(x && dy && red, "xr_affine_act_bwd_reduce: null pointer");
+  XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_reduce: PReLU needs alpha");
+  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, red, nullptr, nullptr, nullptr, coef_per_group};
+  Geo geo = make_geo(G, rows, C, 2048);
+  const size_t smem = (size_t)geo.rpb * C * sizeof(float);
+  if (dtype == XR_BF16)
+    return launch_aff<bf16_t>(affine_act_bwd_reduce_kernel<bf16_t>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_reduce");
+  return launch_aff<float>(affine_act_bwd_reduce_kernel<float>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_reduce");
+}
+
+extern "C" int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, const float* invstd, float* coef,
+                                  float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, void* stream) {
+  XR_CHECK_ARG(red && mean && invstd && coef && G > 0 && rows > 0 && C > 0, "xr_norm_bwd_coeffs: bad arguments");
+  hipLaunchKernelGGL(norm_bwd_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, gamma, mean, invstd,
+                     coef, dgamma, dbeta, dalpha, G, rows, C);
+  XR_CHECK_LAUNCH("xr_norm_bwd_coeffs");
+  return XR_OK;
+}
+
+extern "C" int xr_reduce_groups(const float* red, float* out, int G, int C, int accumulate, void* stream) {
+  XR_CHECK_ARG(red && out && G > 0 && C > 0, "xr_reduce_groups: bad arguments");
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, out, G, C, accumulate);
+  XR_CHECK_LAUNCH("xr_reduce_groups");
+  return XR_OK;
+}
+
+extern "C" int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                       const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
+                                       int G, int rows, int C, int coef_per_group, void* stream) {
+  if (int e = check_geo("xr_affine_act_bwd_apply", dtype, G, rows, C)) return e;
+  XR_CHECK_ARG(x && dy && (dx || dres), "xr_affine_act_bwd_apply: null pointer");
+  XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_apply: PReLU needs alpha");
+  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, dres, coef_per_group};
+  Geo geo = make_geo(G, rows, C, 4096);
+  if (dtype == XR_BF16)
+    return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
+  return launch_aff<float>(affine_act_bwd_apply_kernel<float>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
+}
+
+extern "C" int xr_se_excite_fwd(const float* pooled_sum, const float* w1, const float* w2, float* hidden, float* s, int N,
+                                int C, int Cr, float inv_hw, void* stream) {
+  XR_CHECK_ARG(pooled_sum && w1 && w2 && hidden && s && N > 0 && C > 0 && Cr > 0 && C <= 4096, "xr_se_excite_fwd: bad arguments");
+  hipLaunchKernelGGL(se_excite_fwd_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, pooled_sum, w1, w2,
+                     hidden, s, C, Cr, inv_hw);
+  XR_CHECK_LAUNCH("xr_se_excite_fwd");
+  return XR_OK;
+}
+
+extern "C" int xr_se_excite_bwd(const float* w1, const float* w2, const float* hidden, const float* s, const float* ds,
+                                float* dpre2, float* dhid, float* dpooled, int N, int C, int Cr, float inv_hw, void* stream) {
+  XR_CHECK_ARG(w1 && w2 && hidden && s && ds && dpre2 && dhid && dpooled && N > 0 && C > 0 && Cr > 0 && C <= 4096,
+               "xr_se_excite_bwd: bad arguments");
+  hipLaunchKernelGGL(se_excite_bwd_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, w1, w2, hidden, s,
+                     ds, dpre2, dhid, dpooled, C, Cr, inv_hw);
+  XR_CHECK_LAUNCH("xr_se_excite_bwd");
+  return XR_OK;
+}
+
+extern "C" int xr_small_atb(const float* A, const float* B, float* out, int N, int I, int J, float scale, int accumulate,
+                            void* stream) {
+  XR_CHECK_ARG(A && B && out && N > 0 && I > 0 && J > 0, "xr_small_atb: bad arguments");
+  hipLaunchKernelGGL(small_atb_kernel, dim3(cdiv((long long)I * J, 256)), dim3(256), 0, (hipStream_t)stream, A, B, out, N, I, J,
+                     scale, accumulate);
+  XR_CHECK_LAUNCH("xr_small_atb");
+  return XR_OK;
+}

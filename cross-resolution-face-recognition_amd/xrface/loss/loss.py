@@ -1,0 +1,42 @@
+"""Loss modules on the HIP path -- mirror of /root/reference loss/loss.py."""
+import torch.nn as nn
+
+from .. import ops
+
+
+class MSELossFunc(nn.Module):
+    """97 * mean((input - target)^2)   (reference loss/loss.py:7-15)."""
+
+    def forward(self, input, target):
+        return ops.mse_loss(input, target, 97.0)
+
+
+class MSELoss_Landmark(nn.Module):
+    """97 * mean((sum_c input[:, c] - target)^2)   (reference loss/loss.py:17-32)."""
+
+    def forward(self, input, target):
+        return ops.landmark_loss(input, target, 97.0)
+
+
+class CrossEntropyLoss2d(nn.Module):
+    """NLLLoss(log_softmax(outputs, 1), squeeze(targets))   (reference loss/loss.py:34-62)."""
+
+    def __init__(self, weight=None):
+        super().__init__()
+
+    def forward(self, outputs, targets):
+        return ops.cross_entropy_2d(outputs, targets)
+
+
+class MSELoss(nn.Module):
+    """nn.MSELoss drop-in used as ``criterion`` by distill_main.py:210 / train_FHN.py:189."""
+
+    def forward(self, input, target):
+        return ops.mse_loss(input, target, 1.0)
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss drop-in for (N, C) logits (main.py:132)."""
+
+    def forward(self, input, target):
+        return ops.cross_entropy(input, target)

@@ -1,0 +1,146 @@
+"""Parameter-holder layers: genuine ``torch.nn`` subclasses (so ``isinstance(m, nn.Conv2d)`` checks in the
+reference's ``weights_init`` -- Face_Hallucination_sub_Net.py:368-380 -- and ``state_dict`` keys keep working)
+whose compute runs on the HIP path.
+
+Each layer has two entry points:
+  ``f(buf, ...)``   internal: NHWC buffer in, NHWC buffer out (used by the fused model forwards);
+  ``forward(x)``    user-facing: logical NCHW tensor in/out (used when a script calls a child directly, e.g.
+                    ``backbone.input_layer(x)`` in SUPER_RESOLUTION/train_FHN.py:255).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import enter, leave, leave2d
+
+
+class Conv2d(nn.Conv2d):
+    def f(self, buf):
+        assert self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.groups == 1 \
+            and self.dilation == (1, 1), "xrface.Conv2d: square stride/padding, no groups/dilation"
+        return ops.conv2d(buf, self.weight, self.bias, self.stride[0], self.padding[0])
+
+    def forward(self, x):
+        return leave(self.f(enter(x)), self.out_channels)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def f(self, buf):
+        return ops.conv_transpose2d(buf, self.weight, self.bias, self.stride[0], self.padding[0], self.output_padding[0])
+
+    def forward(self, x, output_size=None):
+        return leave(self.f(enter(x)), self.out_channels)
+
+
+class Linear(nn.Linear):
+    def f(self, buf):
+        """buf: [N,H,W,C] NHWC feature map (flattened in the reference's C,H,W order by the weight pack)."""
+        return ops.linear_nhwc(buf, self.weight, self.bias)
+
+    def forward(self, x):
+        if x.dim() == 4:
+            return leave2d(self.f(enter(x)))[:, :self.out_features]
+        n, feat = x.shape
+        buf = enter(x.reshape(n, feat, 1, 1))
+        return leave2d(self.f(buf))[:, :self.out_features]
+
+
+class InstanceNorm2d(nn.InstanceNorm2d):
+    """eps 1e-5, no running statistics (model/FSRnet.py:81,112): identical in train and eval."""
+
+    def f(self, buf, res=None, act=None, alpha=None):
+        assert not self.track_running_stats
+        return ops.norm_act(buf, self.weight, self.bias, None, None, res, alpha, "in", act, True, 0.0, self.eps)
+
+    def forward(self, x):
+        return leave(self.f(enter(x)))
+
+
+class _BNMixin:
+    def f(self, buf, res=None, act=None, alpha=None):
+        training = self.training or not self.track_running_stats
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        mom = 0.1 if self.momentum is None else self.momentum
+        return ops.norm_act(buf, self.weight, self.bias, self.running_mean, self.running_var, res, alpha, "bn", act, training,
+                            mom, self.eps)
+
+
+class BatchNorm2d(_BNMixin, nn.BatchNorm2d):
+    def forward(self, x):
+        return leave(self.f(enter(x)))
+
+
+class BatchNorm1d(_BNMixin, nn.BatchNorm1d):
+    def forward(self, x):
+        assert x.dim() == 2
+        return leave2d(self.f(enter(x)))
+
+
+class PReLU(nn.PReLU):
+    def f(self, buf, res=None):
+        return ops.norm_act(buf, res=res, alpha=self.weight, mode="none", act="prelu")
+
+    def forward(self, x):
+        if x.dim() == 2:
+            return leave2d(self.f(enter(x)))
+        return leave(self.f(enter(x)))
+
+
+class ReLU(nn.ReLU):
+    def f(self, buf, res=None):
+        return ops.norm_act(buf, res=res, mode="none", act="relu")
+
+    def forward(self, x):
+        if x.dim() == 2:
+            return leave2d(self.f(enter(x)))
+        return leave(self.f(enter(x)))
+
+
+class Dropout(nn.Dropout):
+    """Dropout(p) with a counter-based stream; ``inject_mask`` (uint8, NHWC layout of the input buffer) pins it
+    for parity tests."""
+
+    inject_mask = None
+
+    def f(self, buf):
+        return ops.dropout(buf, self.p, self.training, self.inject_mask)
+
+    def forward(self, x):
+        if x.dim() == 2:
+            return leave2d(self.f(enter(x)))
+        return leave(self.f(enter(x)))
+
+
+class MaxPool2d(nn.MaxPool2d):
+    """Only the two forms the hot path uses: MaxPool2d(1, stride) (pure sub-sampling, model_irse.py:53)
+    and MaxPool2d(2, 2)."""
+
+    def f(self, buf):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        s = self.stride if isinstance(self.stride, int) else self.stride[0]
+        if k == 1:
+            return ops.subsample(buf, s)
+        if k == 2 and s == 2:
+            return ops.maxpool2(buf)
+        raise RuntimeError(f"xrface.MaxPool2d: unsupported kernel {k} / stride {s}")
+
+    def forward(self, x):
+        return leave(self.f(enter(x)))
+
+
+class Flatten(nn.Module):
+    """input.view(N, -1) in C,H,W order (model_irse.py:11-13); materialises the permutation when handed a
+    channels_last view (the fused Backbone.forward never calls this -- it folds the order into the weight pack)."""
+
+    def forward(self, x):
+        return x.reshape(x.size(0), -1)
+
+
+def run_seq(seq, buf):
+    """Run an nn.Sequential of xrface layers on an NHWC buffer."""
+    for m in seq:
+        buf = m.f(buf)
+    return buf

@@ -1,0 +1,766 @@
+"""torch.autograd.Function wrappers over the C ABI (include/xrface.h).
+
+Internal activations are explicit NHWC buffers ``[N, H, W, Cp]`` (Cp = channel pitch, a multiple of 8,
+zero padded) in bf16 or fp32; the autograd graph is built on those buffers.  ``enter``/``leave``
+convert at module boundaries (zero-copy for feature maps whose channel count is a multiple of 8).
+Every op fails loudly when the HIP library is unavailable -- there is no CPU path here.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, XR_BF16, XR_F32, dt, lib, ptr, stream
+
+EPS = 1e-5
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": 1024}
+
+
+def set_compute_dtype(dtype):
+    """Activation dtype chosen at module entry for fp32 NCHW inputs: torch.float32 (parity mode: split-bf16
+    MFMA, ~fp32 accuracy) or torch.bfloat16 (throughput mode)."""
+    assert dtype in (torch.float32, torch.bfloat16)
+    _cfg["compute_dtype"] = dtype
+
+
+def get_compute_dtype():
+    return _cfg["compute_dtype"]
+
+
+def r8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def kg_of(taps: int, cp: int) -> int:
+    return (taps * cp + 63) // 64 * 64
+
+
+def _need_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("xrface: tensors must live on a ROCm device (no CPU fallback on the product path)")
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------- weight packs
+_pack_cache: dict = {}
+_pack_epoch = [0]
+
+
+def invalidate_weight_cache():
+    """Fused optimizers update parameters through raw pointers (no version bump): they call this."""
+    _pack_epoch[0] += 1
+    if len(_pack_cache) > 4096:
+        _pack_cache.clear()
+
+
+def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
+    """Pack an fp32 parameter for the implicit-GEMM kernels (cached per parameter version)."""
+    key = (w.data_ptr(), kind, dtype, Bp)
+    tag = (w._version, _pack_epoch[0], tuple(w.shape))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2], hit[3]
+    kg = kg_of(taps, Bp)
+    rows = A1 * A2
+    hi = torch.empty((rows, kg), dtype=torch.bfloat16, device=w.device)
+    lo = torch.empty((rows, kg), dtype=torch.bfloat16, device=w.device) if dtype == torch.float32 else None
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    lib.xr_pack_weight(ptr(wd), ptr(hi), ptr(lo), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, stream())
+    _pack_cache[key] = (tag, hi, lo, kg)
+    return hi, lo, kg
+
+
+def _wgrad_split(M, K, kg):
+    tiles = ((K + 127) // 128) * ((kg + 127) // 128) if K > 64 else ((kg + 255) // 256)
+    steps = (M + 63) // 64
+    return max(1, min(steps, _cfg["wgrad_blocks"] // max(tiles, 1)))
+
+
+# ------------------------------------------------------------------------------------------------- layout
+class _Enter(Function):
+    """NCHW fp32 (contiguous) -> NHWC compute dtype, channels zero-padded to a multiple of 8."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _need_cuda(x)
+        N, C, H, W = x.shape
+        ctx.shape = (N, C, H, W)
+        xs = _c(x.detach().float())
+        out = torch.empty((N, H, W, r8(C)), dtype=dtype, device=x.device)
+        lib.xr_nchw_to_nhwc(dt(out), ptr(xs), ptr(out), N, C, H, W, r8(C), stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = ctx.shape
+        g = _c(g)
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        lib.xr_nhwc_to_nchw(dt(g), ptr(g), ptr(out), N, C, H, W, g.shape[3], stream())
+        return out, None
+
+
+class _Leave(Function):
+    """NHWC buffer -> plain NCHW fp32 (used for tensors whose channel count is not a multiple of 8)."""
+
+    @staticmethod
+    def forward(ctx, buf, C):
+        N, H, W, Cp = buf.shape
+        ctx.meta = (C, Cp, buf.dtype)
+        out = torch.empty((N, C, H, W), dtype=torch.float32, device=buf.device)
+        lib.xr_nhwc_to_nchw(dt(buf), ptr(buf), ptr(out), N, C, H, W, Cp, stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        C, Cp, dtype = ctx.meta
+        N, _, H, W = g.shape
+        gs = _c(g.float())
+        out = torch.empty((N, H, W, Cp), dtype=dtype, device=g.device)
+        lib.xr_nchw_to_nhwc(dt(out), ptr(gs), ptr(out), N, C, H, W, Cp, stream())
+        return out, None
+
+
+def enter(x, dtype=None):
+    """User tensor (N,C,H,W) or (N,F) -> internal NHWC buffer [N,H,W,Cp].  Zero-copy for channels_last
+    feature maps with C % 8 == 0 already in a compute dtype."""
+    _need_cuda(x)
+    if x.dim() == 2:
+        x = x.reshape(x.shape[0], x.shape[1], 1, 1)
+    if x.dim() != 4:
+        raise RuntimeError(f"xrface: expected a 4-D NCHW tensor, got shape {tuple(x.shape)}")
+    C = x.shape[1]
+    if x.dtype in (torch.float32, torch.bfloat16) and C % 8 == 0 and (dtype is None or dtype == x.dtype):
+        v = x.permute(0, 2, 3, 1)
+        if v.is_contiguous() and v.data_ptr() % 16 == 0:
+            return v
+    return _Enter.apply(x, dtype or _cfg["compute_dtype"])
+
+
+def leave(buf, C=None):
+    """Internal NHWC buffer -> user-facing tensor of logical shape (N,C,H,W): a zero-copy channels_last view
+    when no channel padding is involved, otherwise a plain NCHW fp32 tensor."""
+    Cp = buf.shape[3]
+    C = Cp if C is None else C
+    if C == Cp:
+        return buf.permute(0, 3, 1, 2)
+    return _Leave.apply(buf, C)
+
+
+def leave2d(buf):
+    """[N,1,1,C] -> (N, C)."""
+    return buf.reshape(buf.shape[0], buf.shape[3])
+
+
+# ------------------------------------------------------------------------------------------------- convolution
+def _bias_grad(dy, K):
+    N, Ho, Wo, Kp = dy.shape
+    sums = torch.zeros((2, 1, Kp), dtype=torch.float32, device=dy.device)
+    lib.xr_group_stats(dt(dy), ptr(dy), ptr(sums), 1, N * Ho * Wo, Kp, stream())
+    return sums[0, 0, :K].clone()
+
+
+class _Conv2d(Function):
+    """aten::conv2d replacement (weight [K][C][R][S] fp32 Parameter; x NHWC buffer)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        _need_cuda(x)
+        x = _c(x)
+        N, H, W, Cp = x.shape
+        K, C, R, S = w.shape
+        assert r8(C) == Cp, f"conv: input pitch {Cp} does not match weight C={C}"
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        hi, lo, kg = _packed(w, "fwd", x.dtype, K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
+        Kp = r8(K)
+        y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
+        bf = None if b is None else _c(b.detach().float())
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(hi), ptr(lo), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
+                          kg, Kp, stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, pad, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_b = ctx.geom
+        dy = _c(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        N, H, W, Cp = x.shape
+        K, C, R, S = w.shape
+        _, Ho, Wo, Kp = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            hi, lo, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
+            dx = torch.empty_like(x)
+            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(hi), ptr(lo), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
+                              kg, Cp, stream())
+        if ctx.needs_input_grad[1]:
+            kg = kg_of(R * S, Cp)
+            dwp = torch.zeros((K, kg), dtype=torch.float32, device=x.device)
+            lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg,
+                              _wgrad_split(N * Ho * Wo, K, kg), stream())
+            dw = torch.empty_like(w, dtype=torch.float32)
+            lib.xr_unpack_wgrad(ptr(dwp), ptr(dw), K, 1, R * S, C, Cp, kg, C * R * S, 0, 1, R * S, 0, stream())
+        if has_b and ctx.needs_input_grad[2]:
+            db = _bias_grad(dy, K)
+        return dx, dw, db, None, None
+
+
+class _ConvTranspose2d(Function):
+    """aten::conv_transpose2d replacement (weight [Cin][Cout][R][S]); model/FSRnet.py:436."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, out_pad):
+        x = _c(x)
+        N, H, W, Cp = x.shape
+        Cin, Cout, R, S = w.shape
+        assert r8(Cin) == Cp
+        Ho, Wo = (H - 1) * stride - 2 * pad + R + out_pad, (W - 1) * stride - 2 * pad + S + out_pad
+        assert (Ho + 2 * pad - R) // stride + 1 == H and (Wo + 2 * pad - S) // stride + 1 == W, \
+            "deconv geometry not expressible as the transposed gather"
+        hi, lo, kg = _packed(w, "tfwd", x.dtype, Cout, 1, R * S, Cin, Cp, R * S, 0, 1, Cout * R * S)
+        Kp = r8(Cout)
+        y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
+        bf = None if b is None else _c(b.detach().float())
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(hi), ptr(lo), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
+                          kg, Kp, stream())
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, pad, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_b = ctx.geom
+        dy = _c(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        N, H, W, Cp = x.shape
+        Cin, Cout, R, S = w.shape
+        _, Ho, Wo, Kp = dy.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx[n,hi,wi,ci] = sum dy[n, hi*s - p + r, ., co] w[ci][co][r][s]: an ordinary strided conv over dy
+            hi, lo, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
+            dx = torch.empty_like(x)
+            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(hi), ptr(lo), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
+                              kg, Cp, stream())
+        if ctx.needs_input_grad[1]:
+            # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
+            kg = kg_of(R * S, Cp)
+            dwp = torch.zeros((Cout, kg), dtype=torch.float32, device=x.device)
+            lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1, Kp, kg,
+                              _wgrad_split(N * Ho * Wo, Cout, kg), stream())
+            dw = torch.empty_like(w, dtype=torch.float32)
+            lib.xr_unpack_wgrad(ptr(dwp), ptr(dw), Cout, 1, R * S, Cin, Cp, kg, R * S, 0, 1, Cout * R * S, 0, stream())
+        if has_b and ctx.needs_input_grad[2]:
+            db = _bias_grad(dy, Cout)
+        return dx, dw, db, None, None, None
+
+
+class _LinearNHWC(Function):
+    """Flatten(C,H,W order) + nn.Linear on an NHWC buffer == a full-extent H x W convolution
+    (model_irse.py:146-147, model/resnet.py:221-222).  x: [N,H,W,C] with C % 8 == 0; returns [N,1,1,Kp]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = _c(x)
+        N, H, W, C = x.shape
+        K, F = w.shape
+        assert F == C * H * W, f"linear: in_features {F} != {C}*{H}*{W}"
+        HW = H * W
+        hi, lo, kg = _packed(w, "lin_fwd", x.dtype, K, 1, HW, C, C, C * HW, 0, 1, HW)
+        Kp = r8(K)
+        y = torch.empty((N, 1, 1, Kp), dtype=x.dtype, device=x.device)
+        bf = None if b is None else _c(b.detach().float())
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(hi), ptr(lo), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, stream())
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        N, H, W, C = x.shape
+        K, F = w.shape
+        HW, Kp = H * W, dy.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # plain GEMM dx[n][p*C + c] = sum_k dy[n][k] w[k][c*HW + p]: a 1x1 "conv" with HW*C output channels
+            hi, lo, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
+            dx = torch.empty_like(x)
+            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(hi), ptr(lo), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
+                              HW * C, stream())
+        if ctx.needs_input_grad[1]:
+            kg = kg_of(HW, C)
+            dwp = torch.zeros((K, kg), dtype=torch.float32, device=x.device)
+            lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, stream())
+            dw = torch.empty_like(w, dtype=torch.float32)
+            lib.xr_unpack_wgrad(ptr(dwp), ptr(dw), K, 1, HW, C, C, kg, C * HW, 0, 1, HW, 0, stream())
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = _bias_grad(dy, K)
+        return dx, dw, db
+
+
+def conv2d(x, w, b=None, stride=1, pad=0):
+    return _Conv2d.apply(x, w, b, stride, pad)
+
+
+def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0):
+    return _ConvTranspose2d.apply(x, w, b, stride, pad, out_pad)
+
+
+def linear_nhwc(x, w, b=None):
+    return _LinearNHWC.apply(x, w, b)
+
+
+# ------------------------------------------------------------------------------------------------- norm + act
+_ACT = {None: ACT_NONE, "none": ACT_NONE, "prelu": ACT_PRELU, "relu": ACT_RELU}
+
+
+class _NormAct(Function):
+    """y = act(norm(x) + res).  mode: 'in' (InstanceNorm2d), 'bn' (BatchNorm, batch statistics when
+    ``training``), 'none' (activation / residual add only)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps):
+        x = _c(x)
+        N, H, W, C = x.shape
+        if res is not None:
+            res = _c(res)
+            assert res.shape == x.shape and res.dtype == x.dtype
+        dev = x.device
+        stats = mode == "in" or (mode == "bn" and training)
+        G, rows = (N, H * W) if mode == "in" else (1, N * H * W)
+        f32 = dict(dtype=torch.float32, device=dev)
+        gm = None if gamma is None else _c(gamma.detach().float())
+        bt = None if beta is None else _c(beta.detach().float())
+        al = None if alpha is None else _c(alpha.detach().float())
+        mean = invstd = scale = shift = None
+        if stats:
+            sums = torch.zeros((2, G, C), **f32)
+            lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
+            mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
+            scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
+            upd = mode == "bn" and rmean is not None
+            lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                 ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum, stream())
+        elif mode == "bn":
+            scale, shift = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
+            lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
+        y = torch.empty_like(x)
+        a = _ACT[act]
+        lib.xr_affine_act(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), G, rows, C, 1, stream())
+        ctx.save_for_backward(x, res, scale, shift, mean, invstd, gm, al, rmean, rvar)
+        ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, res, scale, shift, mean, invstd, gm, al, rmean, rvar = ctx.saved_tensors
+        mode, a, stats, G, rows, C, eps, has_g, has_b, has_a = ctx.meta
+        dy = _c(dy)
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        f32 = dict(dtype=torch.float32, device=x.device)
+        red = torch.zeros((3, G, C), **f32)
+        lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red), G, rows, C,
+                                     1, stream())
+        dgamma = dbeta = dalpha = None
+        coef = None
+        if stats:
+            coef = torch.empty((3, G, C), **f32)
+            dgamma = torch.zeros(C, **f32) if has_g else None
+            dbeta = torch.zeros(C, **f32) if has_b else None
+            dalpha = torch.zeros(C, **f32) if has_a else None
+            lib.xr_norm_bwd_coeffs(ptr(red), ptr(gm), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dalpha),
+                                   G, rows, C, stream())
+        else:
+            if has_a:
+                dalpha = torch.empty(C, **f32)
+                lib.xr_reduce_groups(ptr(red[2]), ptr(dalpha), G, C, 0, stream())
+            if mode == "bn":
+                if has_b:
+                    dbeta = red[0, 0].clone()
+                if has_g:
+                    dgamma = (red[1, 0] - rmean * red[0, 0]) * torch.rsqrt(rvar + eps)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[5]) else None
+        if dx is not None or dres is not None:
+            lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
+                                        ptr(dres), G, rows, C, 1, stream())
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None
+
+
+def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,
+             momentum=0.1, eps=EPS):
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps)
+
+
+# ------------------------------------------------------------------------------------------------- SE
+class _SEScaleAdd(Function):
+    """out = r * sigmoid(fc2(relu(fc1(avgpool(r))))) + shortcut   (SEModule + residual add,
+    model_irse.py:38-46,88-91).  w1: [Cr][C][1][1], w2: [C][Cr][1][1]."""
+
+    @staticmethod
+    def forward(ctx, r, w1, w2, shortcut):
+        r = _c(r)
+        N, H, W, C = r.shape
+        Cr = w1.shape[0]
+        f32 = dict(dtype=torch.float32, device=r.device)
+        sums = torch.zeros((2, N, C), **f32)
+        lib.xr_group_stats(dt(r), ptr(r), ptr(sums), N, H * W, C, stream())
+        w1f, w2f = _c(w1.detach().float()), _c(w2.detach().float())
+        hidden, s = torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
+        inv_hw = 1.0 / (H * W)
+        lib.xr_se_excite_fwd(ptr(sums[0]), ptr(w1f), ptr(w2f), ptr(hidden), ptr(s), N, C, Cr, inv_hw, stream())
+        sc = None if shortcut is None else _c(shortcut)
+        y = torch.empty_like(r)
+        lib.xr_affine_act(dt(r), ptr(r), ptr(s), None, ptr(sc), None, ACT_NONE, ptr(y), N, H * W, C, 1, stream())
+        ctx.save_for_backward(r, w1f, w2f, hidden, s, sums)
+        ctx.inv_hw = inv_hw
+        ctx.has_sc = shortcut is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        r, w1f, w2f, hidden, s, sums = ctx.saved_tensors
+        dy = _c(dy)
+        if dy.dtype != r.dtype:
+            dy = dy.to(r.dtype)
+        N, H, W, C = r.shape
+        Cr = hidden.shape[1]
+        f32 = dict(dtype=torch.float32, device=r.device)
+        red = torch.zeros((3, N, C), **f32)
+        # act none, no shift/res: dz = dy, red[1] = sum dy * r = ds
+        lib.xr_affine_act_bwd_reduce(dt(r), ptr(r), None, None, None, None, ACT_NONE, ptr(dy), ptr(red), N, H * W, C, 1, stream())
+        dpre2, dhid = torch.empty((N, C), **f32), torch.empty((N, Cr), **f32)
+        coef = torch.zeros((3, N, C), **f32)
+        coef[0].copy_(s)
+        lib.xr_se_excite_bwd(ptr(w1f), ptr(w2f), ptr(hidden), ptr(s), ptr(red[1]), ptr(dpre2), ptr(dhid), ptr(coef[2]), N, C, Cr,
+                             ctx.inv_hw, stream())
+        dr = torch.empty_like(r)
+        lib.xr_affine_act_bwd_apply(dt(r), ptr(r), None, None, None, None, ACT_NONE, ptr(dy), ptr(coef), ptr(dr), None, N, H * W, C,
+                                    1, stream())
+        dw1 = torch.empty((Cr, C, 1, 1), **f32)
+        dw2 = torch.empty((C, Cr, 1, 1), **f32)
+        lib.xr_small_atb(ptr(dhid), ptr(sums[0]), ptr(dw1), N, Cr, C, ctx.inv_hw, 0, stream())
+        lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 0, stream())
+        return dr, dw1, dw2, (dy if ctx.has_sc else None)
+
+
+def se_scale_add(r, w1, w2, shortcut=None):
+    return _SEScaleAdd.apply(r, w1, w2, shortcut)
+
+
+# ------------------------------------------------------------------------------------------------- resampling
+class _Subsample(Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        x = _c(x)
+        N, H, W, C = x.shape
+        Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+        y = torch.empty((N, Ho, Wo, C), dtype=x.dtype, device=x.device)
+        lib.xr_subsample(dt(x), ptr(x), ptr(y), N, H, W, C, stride, stream())
+        ctx.meta = (N, H, W, C, stride)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, stride = ctx.meta
+        dy = _c(dy)
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib.xr_subsample_bwd(dt(dy), ptr(dy), ptr(dx), N, H, W, C, stride, stream())
+        return dx, None
+
+
+class _MaxPool2(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, H // 2, W // 2, C), dtype=x.dtype, device=x.device)
+        lib.xr_maxpool2(dt(x), ptr(x), ptr(y), N, H, W, C, stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        N, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        lib.xr_maxpool2_bwd(dt(x), ptr(x), ptr(dy), ptr(dx), N, H, W, C, stream())
+        return dx
+
+
+class _UpAdd2(Function):
+    """up1 + nearest_upsample_x2(low) (model/FSRnet.py:210-211)."""
+
+    @staticmethod
+    def forward(ctx, up1, low):
+        up1, low = _c(up1), _c(low)
+        N, H, W, C = up1.shape
+        assert low.shape == (N, H // 2, W // 2, C)
+        y = torch.empty_like(up1)
+        lib.xr_upadd2(dt(up1), ptr(up1), ptr(low), ptr(y), N, H, W, C, stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W, C = dy.shape
+        dlow = torch.empty((N, H // 2, W // 2, C), dtype=dy.dtype, device=dy.device)
+        lib.xr_upadd2_bwd(dt(dy), ptr(dy), ptr(dlow), N, H, W, C, stream())
+        return dy, dlow
+
+
+class _Cat2(Function):
+    """torch.cat((a, b), channel) on NHWC buffers (model/FSRnet.py:505,534)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _c(a), _c(b)
+        N, H, W, Ca = a.shape
+        Cb = b.shape[3]
+        y = torch.empty((N, H, W, Ca + Cb), dtype=a.dtype, device=a.device)
+        M = N * H * W
+        lib.xr_copy_channels(dt(a), ptr(a), Ca, 0, ptr(y), Ca + Cb, 0, M, Ca, stream())
+        lib.xr_copy_channels(dt(a), ptr(b), Cb, 0, ptr(y), Ca + Cb, Ca, M, Cb, stream())
+        ctx.split = (Ca, Cb)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        Ca, Cb = ctx.split
+        dy = _c(dy)
+        N, H, W, _ = dy.shape
+        M = N * H * W
+        da = torch.empty((N, H, W, Ca), dtype=dy.dtype, device=dy.device)
+        db = torch.empty((N, H, W, Cb), dtype=dy.dtype, device=dy.device)
+        lib.xr_copy_channels(dt(dy), ptr(dy), Ca + Cb, 0, ptr(da), Ca, 0, M, Ca, stream())
+        lib.xr_copy_channels(dt(dy), ptr(dy), Ca + Cb, Ca, ptr(db), Cb, 0, M, Cb, stream())
+        return da, db
+
+
+class _Dropout(Function):
+    @staticmethod
+    def forward(ctx, x, p, mask, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        lib.xr_dropout(dt(x), ptr(x), ptr(mask), ptr(y), x.numel(), p, seed, stream())
+        ctx.meta = (p, seed)
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.meta
+        (mask,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        lib.xr_dropout(dt(dy), ptr(dy), ptr(mask), ptr(dx), dy.numel(), p, seed, stream())
+        return dx, None, None, None
+
+
+class _AddSub(Function):
+    @staticmethod
+    def forward(ctx, a, b, sign):
+        a, b = _c(a), _c(b)
+        assert a.shape == b.shape and a.dtype == b.dtype
+        y = torch.empty_like(a)
+        (lib.xr_add if sign > 0 else lib.xr_sub)(dt(a), ptr(a), ptr(b), ptr(y), a.numel(), stream())
+        ctx.sign = sign
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, (dy if ctx.sign > 0 else -dy), None
+
+
+def subsample(x, stride):
+    return x if stride == 1 else _Subsample.apply(x, stride)
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+def upadd2(up1, low):
+    return _UpAdd2.apply(up1, low)
+
+
+def cat2(a, b):
+    return _Cat2.apply(a, b)
+
+
+_drop_counter = [0]
+
+
+def dropout(x, p, training, mask=None, seed=None):
+    """mask: optional uint8 keep-mask laid out like ``x`` (test injection); otherwise a counter-based stream."""
+    if not training or p == 0.0:
+        return x
+    if seed is None:
+        _drop_counter[0] += 1
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + _drop_counter[0]) & 0xFFFFFFFFFFFFFFFF
+    if mask is not None:
+        mask = _c(mask.to(torch.uint8))
+    return _Dropout.apply(x, float(p), mask, int(seed))
+
+
+def sub(a, b):
+    return _AddSub.apply(a, b, -1)
+
+
+def add(a, b):
+    return _AddSub.apply(a, b, 1)
+
+
+# ------------------------------------------------------------------------------------------------- losses
+def _same_layout(a, b):
+    """Two same-shape tensors as flat contiguous memory in a common element order."""
+    if a.dtype != b.dtype:
+        a, b = a.float(), b.float()
+    if a.dtype not in (torch.float32, torch.bfloat16):
+        a, b = a.float(), b.float()
+    if a.stride() == b.stride() and a.is_non_overlapping_and_dense():
+        return a, b
+    return a.contiguous(), b.contiguous()
+
+
+class _MSE(Function):
+    """scale * mean((a-b)^2): MSELossFunc (scale 97) loss/loss.py:14 and nn.MSELoss (scale 1)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        _need_cuda(a)
+        assert a.shape == b.shape, f"mse: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
+        a2, b2 = _same_layout(a.detach(), b.detach())
+        loss = torch.zeros((), dtype=torch.float32, device=a.device)
+        n = a2.numel()
+        lib.xr_loss_mse(dt(a2), ptr(a2), ptr(b2), scale, 1.0, ptr(loss), None, None, n, n, None, stream())
+        ctx.save_for_backward(a2, b2)
+        ctx.meta = (scale, a.dtype, b.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, b2 = ctx.saved_tensors
+        scale, adt, bdt = ctx.meta
+        g = _c(g.float())
+        da = torch.empty_like(a2) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b2) if ctx.needs_input_grad[1] else None
+        n = a2.numel()
+        lib.xr_loss_mse(dt(a2), ptr(a2), ptr(b2), scale, 1.0, None, ptr(da), ptr(db), n, n, ptr(g), stream())
+        if da is not None and da.dtype != adt:
+            da = da.to(adt)
+        if db is not None and db.dtype != bdt:
+            db = db.to(bdt)
+        return da, db, None
+
+
+class _Landmark(Function):
+    """MSELoss_Landmark (loss/loss.py:28-31); pred NCHW fp32, target (N,H,W) fp32."""
+
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        _need_cuda(pred)
+        p = _c(pred.detach().float())
+        t = _c(target.detach().float())
+        N, C, H, W = p.shape
+        assert t.numel() == N * H * W
+        loss = torch.zeros((), dtype=torch.float32, device=p.device)
+        lib.xr_loss_landmark(ptr(p), ptr(t), scale, 1.0, ptr(loss), None, N, C, H * W, None, stream())
+        ctx.save_for_backward(p, t)
+        ctx.meta = (scale, pred.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        scale, pdt = ctx.meta
+        g = _c(g.float())
+        N, C, H, W = p.shape
+        dp = torch.empty_like(p)
+        lib.xr_loss_landmark(ptr(p), ptr(t), scale, 1.0, None, ptr(dp), N, C, H * W, ptr(g), stream())
+        return dp.to(pdt), None, None
+
+
+class _CE2d(Function):
+    """CrossEntropyLoss2d (loss/loss.py:61-62): NLL(log_softmax(pred, 1), squeeze(target)); NCHW fp32."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _need_cuda(pred)
+        p = _c(pred.detach().float())
+        N, C, H, W = p.shape
+        t = _c(target.detach().reshape(N, H * W).long())
+        loss = torch.zeros((), dtype=torch.float32, device=p.device)
+        lib.xr_loss_ce_nchw(ptr(p), ptr(t), 1.0, ptr(loss), None, N, C, H * W, None, stream())
+        ctx.save_for_backward(p, t)
+        ctx.pdt = pred.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        g = _c(g.float())
+        N, C, H, W = p.shape
+        dp = torch.empty_like(p)
+        lib.xr_loss_ce_nchw(ptr(p), ptr(t), 1.0, None, ptr(dp), N, C, H * W, ptr(g), stream())
+        return dp.to(ctx.pdt), None
+
+
+class _CERows(Function):
+    """nn.CrossEntropyLoss on (M, C) logits (main.py:132; train_teacher_model.py:190)."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        _need_cuda(logits)
+        x = logits.detach()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = _c(x)
+        M, C = x.shape
+        t = _c(target.detach().long())
+        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        lib.xr_loss_softmax_ce(dt(x), ptr(x), ptr(t), 1.0, ptr(loss), None, M, C, C, None, stream())
+        ctx.save_for_backward(x, t)
+        ctx.ldt = logits.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, t = ctx.saved_tensors
+        g = _c(g.float())
+        M, C = x.shape
+        dx = torch.empty_like(x)
+        lib.xr_loss_softmax_ce(dt(x), ptr(x), ptr(t), 1.0, None, ptr(dx), M, C, C, ptr(g), stream())
+        return dx.to(ctx.ldt), None
+
+
+def mse_loss(a, b, scale=1.0):
+    return _MSE.apply(a, b, float(scale))
+
+
+def landmark_loss(pred, target, scale=97.0):
+    return _Landmark.apply(pred, target, float(scale))
+
+
+def cross_entropy_2d(pred, target):
+    return _CE2d.apply(pred, target)
+
+
+def cross_entropy(logits, target):
+    return _CERows.apply(logits, target)

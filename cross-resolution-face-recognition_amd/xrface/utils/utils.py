@@ -1,0 +1,123 @@
+"""Verification metrics on the HIP path -- mirror of /root/reference utils/utils.py:14-87,132-169.
+
+``calculate_roc`` keeps the reference signature and return tuple.  The pair distances and the
+2*K*T threshold re-scans (80 000 numpy passes in the reference) collapse to one HBM pass for the
+distances plus one histogram pass; fold membership is drawn exactly like the reference does it
+(sklearn KFold(shuffle=True) on the global numpy RNG) unless ``fold_id`` is given.  The unused
+O(P^2 log P) ``margin_list`` (utils/utils.py:47-49) is dropped.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .._lib import lib, ptr, stream
+
+
+def pair_dist(embeddings1, embeddings2, device=None):
+    """dist_i = sum_d (e1[i,d] - e2[i,d])^2 on the GPU; accepts numpy arrays or tensors."""
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    e1 = torch.as_tensor(embeddings1, dtype=torch.float32).to(dev).contiguous()
+    e2 = torch.as_tensor(embeddings2, dtype=torch.float32).to(dev).contiguous()
+    assert e1.shape == e2.shape and e1.dim() == 2
+    dist = torch.empty(e1.shape[0], dtype=torch.float32, device=dev)
+    lib.xr_pairdist_l2(ptr(e1), ptr(e2), ptr(dist), e1.shape[0], e1.shape[1], stream())
+    return dist
+
+
+def roc_histograms(dist, actual_issame, fold_id, thresholds, nrof_folds):
+    """int64 [F][2][T+1]: per fold / label, the count of pairs whose first predicted-same threshold index is j."""
+    dev = dist.device
+    thr = torch.as_tensor(np.asarray(thresholds, dtype=np.float32)).to(dev)
+    same = torch.as_tensor(np.asarray(actual_issame).astype(np.uint8)).to(dev)
+    fid = torch.as_tensor(np.asarray(fold_id).astype(np.int32)).to(dev)
+    T = thr.numel()
+    hist = torch.zeros((nrof_folds, 2, T + 1), dtype=torch.int64, device=dev)
+    lib.xr_roc_hist(ptr(dist), ptr(same), ptr(fid), ptr(thr), ptr(hist), dist.numel(), T, nrof_folds, stream())
+    return hist
+
+
+def _rates(tp, fp, tn, fn, n):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tpr = np.where(tp + fn == 0, 0.0, tp.astype(np.float64) / np.maximum(tp + fn, 1))
+        fpr = np.where(fp + tn == 0, 0.0, fp.astype(np.float64) / np.maximum(fp + tn, 1))
+    acc = (tp + tn).astype(np.float64) / float(n)
+    return tpr, fpr, acc
+
+
+def calculate_accuracy(threshold, dist, actual_issame):
+    """reference utils/utils.py:14-24 (host arrays; kept for API compatibility)."""
+    predict_issame = np.less(dist, threshold)
+    tp = np.sum(np.logical_and(predict_issame, actual_issame))
+    fp = np.sum(np.logical_and(predict_issame, np.logical_not(actual_issame)))
+    tn = np.sum(np.logical_and(np.logical_not(predict_issame), np.logical_not(actual_issame)))
+    fn = np.sum(np.logical_and(np.logical_not(predict_issame), actual_issame))
+    tpr = 0 if (tp + fn == 0) else float(tp) / float(tp + fn)
+    fpr = 0 if (fp + tn == 0) else float(fp) / float(fp + tn)
+    acc = float(tp + tn) / dist.size
+    return tpr, fpr, acc
+
+
+def calculate_roc(thresholds, embeddings1, embeddings2, actual_issame, nrof_folds=50, pca=0, fold_id=None):
+    """reference utils/utils.py:26-87 -> (mean tpr[T], mean fpr[T], mean accuracy, best_thresholds[K])."""
+    if pca != 0:
+        raise NotImplementedError("pca > 0 is not on the hot path (distill_main.py:121-136 always passes pca=0)")
+    assert embeddings1.shape[0] == embeddings2.shape[0] and embeddings1.shape[1] == embeddings2.shape[1]
+    thresholds = np.asarray(thresholds)
+    assert np.all(np.diff(thresholds) > 0), "thresholds must be ascending"
+    issame = np.asarray(actual_issame).astype(bool)
+    nrof_pairs = min(len(issame), embeddings1.shape[0])
+    if fold_id is None:
+        from sklearn.model_selection import KFold
+        fold_id = np.empty(nrof_pairs, dtype=np.int32)
+        for f, (_, test_set) in enumerate(KFold(n_splits=nrof_folds, shuffle=True).split(np.arange(nrof_pairs))):
+            fold_id[test_set] = f
+    dist = pair_dist(embeddings1[:nrof_pairs], embeddings2[:nrof_pairs])
+    hist = roc_histograms(dist, issame[:nrof_pairs], fold_id, thresholds, nrof_folds).cpu().numpy()
+    # predicted-same at threshold t  <=>  j <= t  ->  prefix sums over j give tp/fp per fold (test split)
+    cum = np.cumsum(hist, axis=2)[:, :, :-1]            # [F][2][T]
+    tot = hist.sum(axis=2)                               # [F][2]
+    tp_te, fp_te = cum[:, 1, :], cum[:, 0, :]
+    fn_te, tn_te = tot[:, 1, None] - tp_te, tot[:, 0, None] - fp_te
+    tp_all, fp_all = tp_te.sum(0), fp_te.sum(0)
+    pos_all, neg_all = tot[:, 1].sum(), tot[:, 0].sum()
+    nth = len(thresholds)
+    tprs, fprs = np.zeros((nrof_folds, nth)), np.zeros((nrof_folds, nth))
+    accuracy, best_thresholds = np.zeros(nrof_folds), np.zeros(nrof_folds)
+    for f in range(nrof_folds):
+        tp_tr, fp_tr = tp_all - tp_te[f], fp_all - fp_te[f]
+        pos_tr, neg_tr = pos_all - tot[f, 1], neg_all - tot[f, 0]
+        n_tr = pos_tr + neg_tr
+        acc_train = (tp_tr + (neg_tr - fp_tr)).astype(np.float64) / float(n_tr)
+        bi = int(np.argmax(acc_train))
+        best_thresholds[f] = thresholds[bi]
+        n_te = int(tot[f].sum())
+        tprs[f], fprs[f], acc_te = _rates(tp_te[f], fp_te[f], tn_te[f], fn_te[f], n_te)
+        accuracy[f] = acc_te[bi]
+    return np.mean(tprs, 0), np.mean(fprs, 0), accuracy.mean(), best_thresholds
+
+
+class AverageMeter(object):
+    """reference utils/utils.py:132-147."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def accuracy(output, target, topk=(1,)):
+    """reference utils/utils.py:156-169 (top-k precision; host-side bookkeeping)."""
+    maxk = max(topk)
+    batch_size = target.size(0)
+    _, pred = output.float().topk(maxk, 1, True, True)
+    pred = pred.t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / batch_size) for k in topk]

@@ -1,0 +1,223 @@
+/* xrface.h -- C ABI of the MI355X (gfx950) hot-path library for the cross-resolution
+ * face-recognition training/eval path.
+ *
+ * The reference (HyoKong/Cross-Resolution-Face-Recognition) has NO native code and no FFI: its
+ * only "operator API" is the PyTorch nn.Module / ATen op protocol.  Each
+ * entry point below therefore cites the ATen op call site in the reference that it replaces.
+ * The Python host (cross-resolution-face-recognition_amd/xrface) binds these with ctypes and wraps
+ * them in torch.autograd.Function objects living inside nn.Module subclasses that keep the
+ * reference's class names, constructor signatures, forward tuples and state_dict keys.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator); the library
+ *     never allocates or frees device memory and keeps no mutable global state;
+ *   - activations are NHWC ("channels_last"): [N][H][W][C], C innermost;
+ *   - dtype: XR_BF16 (bf16 storage, fp32 accumulate on MFMA) or XR_F32 (fp32 storage; the matrix
+ *     products run as 3-term split-bf16 MFMA with fp32 accumulate, ~2^-16 relative per product);
+ *   - stream: hipStream_t passed as void*; work is enqueued on it and never synchronised;
+ *   - return: 0 on success, negative XR_E_* otherwise; xr_last_error() gives a thread-local
+ *     message.  No C++ exception crosses the boundary.  All entry points are re-entrant.
+ */
+#ifndef XRFACE_H
+#define XRFACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XR_OK 0
+#define XR_E_INVALID (-1)   /* bad argument / unsupported shape */
+#define XR_E_LAUNCH (-2)    /* HIP launch error */
+#define XR_E_NODEVICE (-3)  /* no usable gfx950 device */
+
+#define XR_BF16 0
+#define XR_F32 1
+
+#define XR_ACT_NONE 0
+#define XR_ACT_PRELU 1  /* per-channel slope */
+#define XR_ACT_RELU 2
+
+const char* xr_last_error(void);
+int xr_version(void);
+/* number of CUs of the current device (used by hosts to size split factors); <0 on error */
+int xr_device_cus(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  Parameters stay fp32 nn.Parameters in the reference layouts
+ * (Conv2d [K][C][R][S], model/FSRnet.py:79; ConvTranspose2d [Cin][Cout][R][S], model/FSRnet.py:436;
+ * Linear [K][C*H*W], model_irse.py:147).  Before a step the host packs them for the implicit-GEMM
+ * kernels:   dst[a][t*Bp + b] = src[a1*sa1 + a2*sa2 + t*st + b*sb],  a = a1*A2 + a2,
+ * rows padded with zeros to Kg (multiple of 64), b padded to Bp (multiple of 8).
+ * dst_lo == NULL -> single bf16 plane; otherwise (hi, lo) split planes for XR_F32 mode. */
+int xr_pack_weight(const float* src, void* dst_hi, void* dst_lo, int A1, int A2, int taps, int B, int Bp, int Kg,
+                   int64_t sa1, int64_t sa2, int64_t st, int64_t sb, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution (MFMA 32x32x16 bf16, LDS-staged NHWC tiles).
+ * Replaces aten::conv2d / conv_transpose2d / linear forward and input-gradient:
+ *   model/FSRnet.py:79,85,110,312,318,345,351,384,391,392,432,436,439; model_irse.py:56-60,140,147;
+ *   model/resnet.py:9-16,158,170.
+ * out[n,ho,wo,k] = bias[k] + sum_{r,s,c} in[n, hi, wi, c] * wpack[k][(r*S+s)*C + c]
+ *   transposed == 0:  hi = ho*stride - pad + r                      (conv forward)
+ *   transposed == 1:  hi = (ho + pad - r)/stride when divisible     (conv dgrad / deconv forward)
+ * in: [N][H][W][C] (C % 8 == 0), out: [N][Ho][Wo][K] with row pitch ldo (elements) at channel
+ * offset 0 of the caller's pointer (lets producers write into a concat buffer). */
+int xr_conv_igemm(int dtype, const void* in, const void* w_hi, const void* w_lo, const float* bias, void* out,
+                  int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
+                  int transposed, int Kg, int ldo, void* stream);
+
+/* Weight gradient (aten::convolution_backward weight part; same call sites as above).
+ * dwp[k][t*C + c] += sum_m dy[m][k] * gather(in)[m][t][c]      (fp32, PACKED layout [K][Kg], atomics;
+ * the caller zeroes dwp) where m runs over the N*Ho*Wo pixels of dy (row pitch ldy) and gather()
+ * is the same (transposed) tap gather as xr_conv_igemm on `in` [N][H][W][C].
+ * split = number of pixel-range splits (>= 1) the reduction is spread over. */
+int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,
+                  int Wo, int K, int R, int S, int stride, int pad, int transposed, int ldy, int Kg, int split,
+                  void* stream);
+/* Inverse of xr_pack_weight for gradients: dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= packed[a][t*Bp + b]. */
+int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,
+                    int64_t sa1, int64_t sa2, int64_t st, int64_t sb, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Normalisation / activation family.  Tensors are [G][rows][C] (G groups of `rows` pixels):
+ * BatchNorm2d/1d: G = 1, rows = N*H*W (model_irse.py:56-60,141,144,148; model/resnet.py:24,27,159,167,173);
+ * InstanceNorm2d: G = N, rows = H*W (model/FSRnet.py:81,87,112,115,319,347,385,434);
+ * SE squeeze (AdaptiveAvgPool2d(1), model_irse.py:26): G = N, sums only. */
+
+/* sums[0][g][c] += sum x, sums[1][g][c] += sum x^2 (fp32; caller zeroes `sums`, 2*G*C floats). */
+int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C, void* stream);
+
+/* From sums: mean/invstd (biased variance, eps), scale = gamma*invstd, shift = beta - mean*scale
+ * (gamma/beta NULL -> 1/0).  If running_mean/var != NULL (BatchNorm training): running =
+ * (1-momentum)*running + momentum*{mean, unbiased var}.  Outputs [G][C] fp32; gamma/beta are [C]. */
+int xr_norm_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* invstd,
+                     float* scale, float* shift, float* running_mean, float* running_var, int G, int rows, int C,
+                     float eps, float momentum, void* stream);
+
+/* Eval-mode BatchNorm: scale/shift [C] from running statistics. */
+int xr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                      float* scale, float* shift, int C, float eps, void* stream);
+
+/* y = act(x*scale[g][c] + shift[g][c] + res)      (scale/shift/res optional; alpha [C] for PReLU)
+ * aten::batch_norm/instance_norm apply + prelu/relu + add (model/FSRnet.py:90-98,119-135;
+ * model_irse.py:62-66; model/resnet.py:32-47). */
+int xr_affine_act(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                  const float* alpha, int act, void* y, int G, int rows, int C, int coef_per_group, void* stream);
+/* coef_per_group: scale/shift are [G][C] (1) or shared [C] (0) */
+
+/* Backward, pass 1:  z = x*scale+shift+res ; dz = dy*act'(z)
+ *   red[0][g][c] += sum dz ; red[1][g][c] += sum dz*x ; red[2][g][c] += sum dy*z*[z<=0]  (PReLU dalpha)
+ * (3*G*C floats, caller zeroes). */
+int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                             const float* alpha, int act, const void* dy, float* red, int G, int rows, int C,
+                             int coef_per_group, void* stream);
+
+/* Training-norm backward coefficients from pass-1 sums:
+ *   dx = A*dz + B*x + C0 with A = gamma*invstd, B = -gamma*invstd^2*m2, C0 = -A*m1 - B*mean,
+ *   m1 = mean(dz), m2 = mean(dz*xhat);  dgamma[c] += sum_g sum dz*xhat ; dbeta[c] += sum_g sum dz;
+ *   dalpha[c] += sum_g red[2].  coef = [3][G][C] fp32.  dgamma/dbeta/dalpha optional (accumulated). */
+int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, const float* invstd, float* coef,
+                       float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, void* stream);
+
+/* Backward, pass 2: dx = A*dz + B*x + C0  (coef NULL -> dx = dz*scale, or dz when scale NULL);
+ * dres (optional) = dz. */
+int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                            const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
+                            int G, int rows, int C, int coef_per_group, void* stream);
+/* out[c] (+)= sum_g red[g][c]  (PReLU-only dalpha, conv-bias gradients from xr_group_stats sums) */
+int xr_reduce_groups(const float* red, float* out, int G, int C, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SE excitation (model_irse.py:40-46): s[n][c] = sigmoid(W2 relu(W1 (pooled_sum[n]/HW))), Cr = C/16.
+ * bwd: given ds[n][c] -> dpre2[n][c], dhid[n][Cr], dpooled[n][c] (already divided by HW). */
+int xr_se_excite_fwd(const float* pooled_sum, const float* w1, const float* w2, float* hidden, float* s,
+                     int N, int C, int Cr, float inv_hw, void* stream);
+int xr_se_excite_bwd(const float* w1, const float* w2, const float* hidden, const float* s, const float* ds,
+                     float* dpre2, float* dhid, float* dpooled, int N, int C, int Cr, float inv_hw, void* stream);
+/* out[i][j] (+)= scale * sum_n A[n][i]*B[n][j]  -- dW1 = dhid^T pooled, dW2 = dpre2^T hidden */
+int xr_small_atb(const float* A, const float* B, float* out, int N, int I, int J, float scale, int accumulate,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Resampling glue. */
+/* MaxPool2d(1, stride) == strided sub-sampling (model_irse.py:53,73); bwd scatters into zeros. */
+int xr_subsample(int dtype, const void* x, void* y, int N, int H, int W, int C, int stride, void* stream);
+int xr_subsample_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int stride, void* stream);
+/* F.max_pool2d(x,2,2) (model/FSRnet.py:202); bwd routes to the (first) arg-max, recomputed from x. */
+int xr_maxpool2(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int xr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+/* out = up1 + nearest_up2(low) (model/FSRnet.py:210-211); bwd: dlow = 2x2 sum of dy (dup1 = dy). */
+int xr_upadd2(int dtype, const void* up1, const void* low, void* y, int N, int H, int W, int C, void* stream);
+int xr_upadd2_bwd(int dtype, const void* dy, void* dlow, int N, int H, int W, int C, void* stream);
+/* channel-slice copy: dst[m][dst_off + c] = src[m][src_off + c], c < C  (torch.cat, model/FSRnet.py:505,534) */
+int xr_copy_channels(int dtype, const void* src, int lds_, int src_off, void* dst, int ldd, int dst_off, int64_t M,
+                     int C, void* stream);
+/* NCHW fp32 -> NHWC dtype with channel padding to Cp (module entry), and back (module exit). */
+int xr_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int Cp, void* stream);
+int xr_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int Cp, void* stream);
+/* dtype conversion / elementwise add on flat buffers. */
+int xr_cast(int src_dtype, const void* src, int dst_dtype, void* dst, int64_t n, void* stream);
+int xr_add(int dtype, const void* a, const void* b, void* y, int64_t n, void* stream);
+int xr_sub(int dtype, const void* a, const void* b, void* y, int64_t n, void* stream);
+
+/* Dropout(p) (model_irse.py:145): y = x*keep/(1-p); keep from `mask` (uint8, optional) or from the
+ * counter-based generator hash(seed, element index) -- the same function serves backward. */
+int xr_dropout(int dtype, const void* x, const uint8_t* mask, void* y, int64_t n, float p, uint64_t seed,
+               void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses: value ACCUMULATED with atomics into loss[0] (fp32, caller zeroes; NULL = gradient-only launch);
+ * gradient wrt the prediction written to dpred (NULL = value-only launch), multiplied by `gscale` and, when
+ * gscale_dev != NULL, by the upstream gradient scalar read from that device pointer (no host sync).
+ * xr_loss_mse: scale*mean((a-b)^2): MSELossFunc (scale 97, loss/loss.py:14), nn.MSELoss (scale 1).
+ *   da = gscale*2*scale/n*(a-b), db = -da (either may be NULL). */
+int xr_loss_mse(int dtype, const void* a, const void* b, float scale, float gscale, float* loss, void* da, void* db,
+                int64_t n, int64_t n_valid, const float* gscale_dev, void* stream);
+/* n = elements walked (incl. zero channel padding), n_valid = the mean's divisor */
+/* MSELoss_Landmark (loss/loss.py:28-31): scale*mean((sum_c pred[n][c][p] - target[n][p])^2);
+ * pred/dpred NCHW fp32 [N][C][HW] (the 97-channel head leaves the library as plain NCHW), target fp32 [N][HW]. */
+int xr_loss_landmark(const float* pred, const float* target, float scale, float gscale, float* loss, float* dpred,
+                     int N, int C, int HW, const float* gscale_dev, void* stream);
+/* CrossEntropyLoss2d (loss/loss.py:61-62): mean over pixels of -log_softmax(pred[n,:,p])[target[n,p]], NCHW fp32. */
+int xr_loss_ce_nchw(const float* pred, const int64_t* target, float gscale, float* loss, float* dpred, int N, int C,
+                    int HW, const float* gscale_dev, void* stream);
+/* nn.CrossEntropyLoss on rows (main.py:132, train_teacher_model.py:190): pred [M][ld], C valid columns. */
+int xr_loss_softmax_ce(int dtype, const void* pred, const int64_t* target, float gscale, float* loss, void* dpred,
+                       int64_t M, int C, int ld, const float* gscale_dev, void* stream);
+/* Build-defined ArcFace margin (absent from the reference): in-place on cos logits [M][C]:
+ * logits = s*(phi(cos) at target else cos); dlogit scaling handled by xr_arcface_bwd. */
+int xr_arcface_margin(float* cos_logits, const int64_t* target, float* dphi_dcos, int64_t M, int C, float s,
+                      float m, void* stream);
+/* row-wise L2 normalisation y = x/||x|| and its backward (l2_norm, model_irse.py:16-20). */
+int xr_l2norm_rows(const float* x, float* y, float* inv_norm, int64_t M, int C, void* stream);
+int xr_l2norm_rows_bwd(const float* y, const float* inv_norm, const float* dy, float* dx, int64_t M, int C,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused multi-tensor optimizers over flat fp32 buffers (torch.optim semantics):
+ * SGD(momentum, weight_decay) DISTILLATION/train_HRN.py:75-84; RMSprop(alpha, eps, wd)
+ * Face_Hallucination_sub_Net.py:120-124, distill_main.py:222-225; Adam(betas, eps, wd)
+ * SUPER_RESOLUTION/train_FHN.py:115-121. `wd_mask` (optional, uint8 per element) disables decay. */
+int xr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, float wd,
+                const uint8_t* wd_mask, int first_step, void* stream);
+int xr_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float wd,
+                    void* stream);
+int xr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                 float wd, int step, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Verification (utils/utils.py:14-87, distill_main.py:121-136).
+ * dist[i] = sum_d (e1[i][d]-e2[i][d])^2 (fp32). */
+int xr_pairdist_l2(const float* e1, const float* e2, float* dist, int64_t P, int D, void* stream);
+/* hist[fold][label][j] += 1 with j = #{t : thresholds[t] <= dist[i]} in [0,T] (predict_same at t iff j <= t);
+ * thresholds ascending fp32 [T]; fold_id int32 [P] (values < F); hist int64 [F][2][T+1], caller zeroes. */
+int xr_roc_hist(const float* dist, const uint8_t* issame, const int32_t* fold_id, const float* thresholds,
+                unsigned long long* hist, int64_t P, int T, int F, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRFACE_H */
