@@ -22,8 +22,7 @@ constexpr int NT = 256;       // threads per workgroup (4 waves)
 
 struct IgemmP {
   const void* in;
-  const bf16_t* w_hi;
-  const bf16_t* w_lo;
+  const bf16_t* w;  // NS planes of [K][Kg] bf16, plane stride K*Kg
   const float* bias;
   void* out;
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo, M, tiles_n;
@@ -73,18 +72,33 @@ __device__ __forceinline__ bool tap_coord(int oh0, int ow0, int r, int s, int st
 // LDS operand image: rows of 64 bf16 (128 B), 16-B chunk index XOR-swizzled by (row>>1)&7
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
-  unsigned h[4], l[4];
+// fp32 -> NP bf16 planes with x ~= sum_p plane[p] (3 planes carry all 24 significand bits)
+template <int NP>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[NP]) {
+  unsigned w[NP][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    bf16_t h0, l0, h1, l1;
-    split_bf(v[2 * i], h0, l0);
-    split_bf(v[2 * i + 1], h1, l1);
-    h[i] = (unsigned)h0 | ((unsigned)h1 << 16);
-    l[i] = (unsigned)l0 | ((unsigned)l1 << 16);
+    float a = v[2 * i], b = v[2 * i + 1];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const bf16_t ha = f2bf(a), hb = f2bf(b);
+      w[q][i] = (unsigned)ha | ((unsigned)hb << 16);
+      a -= bf2f(ha);
+      b -= bf2f(hb);
+    }
   }
-  hi = make_uint4(h[0], h[1], h[2], h[3]);
-  lo = make_uint4(l[0], l[1], l[2], l[3]);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) pl[q] = make_uint4(w[q][0], w[q][1], w[q][2], w[q][3]);
+}
+
+// split-precision product: all plane pairs (s, t) with s + t < NS, smallest terms first
+template <int NS>
+__device__ __forceinline__ f32x16_t mfma_split(const bf16x8_t (&a)[NS], const bf16x8_t (&b)[NS], f32x16_t acc) {
+#pragma unroll
+  for (int d = NS - 1; d >= 0; --d)
+#pragma unroll
+    for (int s = 0; s <= d; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[d - s], acc, 0, 0, 0);
+  return acc;
 }
 
 // ------------------------------------------------------------------------------------------------ forward/dgrad
@@ -92,7 +106,7 @@ template <int MODE, int BM, int BN, int WM, bool TR>
 __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int NS = MODE ? 2 : 1;
+  constexpr int NS = MODE ? 3 : 1;
   constexpr int RA = BM / 32, RB = BN / 32;
   using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
   using out_t = in_t;
@@ -120,7 +134,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
 
   float a_f[MODE ? RA : 1][8];
   uint4 a_u[MODE ? 1 : RA];
-  uint4 b_hi[RB], b_lo[MODE ? RB : 1];
+  uint4 b_u[NS][RB];
   const int taps = p.R * p.S;
 
   auto load_stage = [&](int kk) {
@@ -151,8 +165,9 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
       const int row = n0 + rbase + 32 * i;
       const bool ok = row < p.K;
       const size_t off = (size_t)row * p.Kg + k0;
-      b_hi[i] = ok ? *reinterpret_cast<const uint4*>(p.w_hi + off) : make_uint4(0, 0, 0, 0);
-      if constexpr (MODE == 1) b_lo[i] = ok ? *reinterpret_cast<const uint4*>(p.w_lo + off) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+        b_u[q][i] = ok ? *reinterpret_cast<const uint4*>(p.w + (size_t)q * p.K * p.Kg + off) : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -161,10 +176,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
     for (int i = 0; i < RA; ++i) {
       const int off = lds_off(rbase + 32 * i, cc);
       if constexpr (MODE == 1) {
-        uint4 hi, lo;
-        split8(a_f[i], hi, lo);
-        *reinterpret_cast<uint4*>(sA + off) = hi;
-        *reinterpret_cast<uint4*>(sA + BM * 128 + off) = lo;
+        uint4 pl[NS];
+        split8<NS>(a_f[i], pl);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint4*>(sA + q * BM * 128 + off) = pl[q];
       } else {
         *reinterpret_cast<uint4*>(sA + off) = a_u[i];
       }
@@ -172,8 +187,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int off = lds_off(rbase + 32 * i, cc);
-      *reinterpret_cast<uint4*>(sB + off) = b_hi[i];
-      if constexpr (MODE == 1) *reinterpret_cast<uint4*>(sB + BN * 128 + off) = b_lo[i];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) *reinterpret_cast<uint4*>(sB + q * BN * 128 + off) = b_u[q][i];
     }
   };
 
@@ -212,13 +227,7 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (MODE == 1) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -241,14 +250,15 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   __syncthreads();
   out_t* __restrict__ out = reinterpret_cast<out_t*>(p.out);
   constexpr int CPR = BN / 8;  // chunks per tile row
+  const int Kw = (p.K + 7) & ~7;
   for (int idx = t; idx < BM * CPR; idx += NT) {
     const int row = idx / CPR, ch = idx - row * CPR;
     const int m = m0 + row;
     const int ncol = n0 + ch * 8;
-    if (m >= p.M || ncol >= p.ldo) continue;
+    if (m >= p.M || ncol >= Kw) continue;  // Kw = K rounded up to 8: padding channels are written as zeros
     const out_t* sp = stage + row * PITCH + ch * 8;
     out_t* dp = out + (size_t)m * p.ldo + ncol;
-    if (ncol + 8 <= p.ldo) {
+    if (ncol + 8 <= Kw) {
       if constexpr (sizeof(out_t) == 2) {
         *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
       } else {
@@ -256,14 +266,14 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
         *reinterpret_cast<float4*>(dp + 4) = *reinterpret_cast<const float4*>(sp + 4);
       }
     } else {
-      for (int e = 0; e < 8 && ncol + e < p.ldo; ++e) dp[e] = sp[e];
+      for (int e = 0; e < 8 && ncol + e < Kw; ++e) dp[e] = sp[e];
     }
   }
 }
 
 template <int MODE, int BM, int BN>
 constexpr size_t igemm_smem() {
-  constexpr int NS = MODE ? 2 : 1;
+  constexpr int NS = MODE ? 3 : 1;
   constexpr size_t ops = (size_t)NS * (BM + BN) * 128;
   constexpr size_t esz = MODE ? 4 : 2;
   constexpr size_t stg = (size_t)BM * (BN + 16 / esz) * esz;
@@ -272,7 +282,7 @@ constexpr size_t igemm_smem() {
 
 template <int MODE, int BM, int BN, int WM, bool TR>
 int launch_igemm(IgemmP& p, hipStream_t st) {
-  p.tiles_n = cdiv(p.ldo < p.K ? p.K : (p.K + 7) / 8 * 8, BN);
+  p.tiles_n = cdiv((p.K + 7) / 8 * 8, BN);
   const int tiles_m = cdiv(p.M, BM);
   constexpr size_t smem = igemm_smem<MODE, BM, BN>();
   auto kern = igemm_kernel<MODE, BM, BN, WM, TR>;
@@ -314,7 +324,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int pitch,
 template <int MODE, int BR, int BC, bool TR>
 __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int BP = 64;  // pixels per stage
-  constexpr int NS = MODE ? 2 : 1;
+  constexpr int NS = MODE ? 3 : 1;
   constexpr int WC = BC / 64, WR = BR / 64;  // wave grid (wave tile 64x64)
   static_assert(WC * WR == 4, "4 waves");
   constexpr int PY = BR * 2 + 64, PX = BC * 2 + 64;  // image pitches: == 64 (mod 256) -> conflict-free tr reads
@@ -386,10 +396,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     for (int i = 0; i < NY; ++i) {
       const int off = (yrow0 + (NT / CRY) * i) * PY + ych * 16;
       if constexpr (MODE == 1) {
-        uint4 hi, lo;
-        split8(y_f[i], hi, lo);
-        *reinterpret_cast<uint4*>(sY + off) = hi;
-        *reinterpret_cast<uint4*>(sY + BP * PY + off) = lo;
+        uint4 pl[NS];
+        split8<NS>(y_f[i], pl);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint4*>(sY + q * BP * PY + off) = pl[q];
       } else {
         *reinterpret_cast<uint4*>(sY + off) = y_u[i];
       }
@@ -398,10 +408,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     for (int i = 0; i < NX; ++i) {
       const int off = (xrow0 + (NT / CRX) * i) * PX + xch * 16;
       if constexpr (MODE == 1) {
-        uint4 hi, lo;
-        split8(x_f[i], hi, lo);
-        *reinterpret_cast<uint4*>(sX + off) = hi;
-        *reinterpret_cast<uint4*>(sX + BP * PX + off) = lo;
+        uint4 pl[NS];
+        split8<NS>(x_f[i], pl);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) *reinterpret_cast<uint4*>(sX + q * BP * PX + off) = pl[q];
       } else {
         *reinterpret_cast<uint4*>(sX + off) = x_u[i];
       }
@@ -441,13 +451,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if constexpr (MODE == 1) {
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][1], fb[j][0], acc[i][j], 0, 0, 0);
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][1], acc[i][j], 0, 0, 0);
-            }
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][0], fb[j][0], acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
       }
       __syncthreads();
     }
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 
 template <int MODE, int BR, int BC, bool TR>
 int launch_wgrad(WgradP& p, int split, hipStream_t st) {
-  constexpr int NS = MODE ? 2 : 1;
+  constexpr int NS = MODE ? 3 : 1;
   constexpr size_t smem = (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64));
   p.tiles_c = cdiv(p.Kg, BC);
   const int tiles_r = cdiv(p.K, BR);
@@ -494,7 +498,7 @@ int launch_wgrad(WgradP& p, int split, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ pack / unpack
-__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, int A2,
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes, int A2,
                                    int taps, int B, int Bp, int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb,
                                    int64_t total) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -506,13 +510,10 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __rest
       const int64_t a1 = a / A2, a2 = a - a1 * A2;
       v = src[a1 * sa1 + a2 * sa2 + tp * st_ + b * sb];
     }
-    if (lo != nullptr) {
-      bf16_t h, l;
-      split_bf(v, h, l);
-      hi[i] = h;
-      lo[i] = l;
-    } else {
-      hi[i] = f2bf(v);
+    for (int q = 0; q < nplanes; ++q) {
+      const bf16_t h = f2bf(v);
+      dst[(int64_t)q * total + i] = h;
+      v -= bf2f(h);
     }
   }
 }
@@ -535,16 +536,15 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __r
 
 }  // namespace
 
-extern "C" int xr_pack_weight(const float* src, void* dst_hi, void* dst_lo, int A1, int A2, int taps, int B, int Bp,
+extern "C" int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int taps, int B, int Bp,
                               int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, void* stream) {
-  XR_CHECK_ARG(src && dst_hi, "xr_pack_weight: null pointer");
+  XR_CHECK_ARG(src && dst && (nplanes == 1 || nplanes == 3), "xr_pack_weight: null pointer or nplanes not in {1,3}");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Bp % 8 == 0 && Kg % 64 == 0 && Kg >= taps * Bp,
                "xr_pack_weight: bad dims A1=%d A2=%d taps=%d B=%d Bp=%d Kg=%d", A1, A2, taps, B, Bp, Kg);
   const int64_t total = (int64_t)A1 * A2 * Kg;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst_hi,
-                     (bf16_t*)dst_lo, A2, taps, B, Bp, Kg, sa1, sa2, st_, sb, total);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, nplanes, A2, taps, B, Bp, Kg, sa1, sa2, st_, sb, total);
   XR_CHECK_LAUNCH("xr_pack_weight");
   return XR_OK;
 }
@@ -562,12 +562,11 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   return XR_OK;
 }
 
-extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w_hi, const void* w_lo, const float* bias, void* out,
+extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                              int transposed, int Kg, int ldo, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
-  XR_CHECK_ARG(in && w_hi && out, "xr_conv_igemm: null pointer");
-  XR_CHECK_ARG(dtype == XR_BF16 || w_lo, "xr_conv_igemm: XR_F32 needs the lo weight plane");
+  XR_CHECK_ARG(in && w && out, "xr_conv_igemm: null pointer");
   XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "xr_conv_igemm: non-positive dimension");
   XR_CHECK_ARG(C % 8 == 0, "xr_conv_igemm: C=%d must be a multiple of 8 (pad channels)", C);
@@ -583,7 +582,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w_hi, const 
                  "xr_conv_igemm(transposed): output %dx%d inconsistent with input %dx%d k%d s%d p%d", Ho, Wo, H, W, R,
                  stride, pad);
   }
-  IgemmP p{in, (const bf16_t*)w_hi, (const bf16_t*)w_lo, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
+  IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
            N * Ho * Wo, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool wide = K > 64;

@@ -45,34 +45,33 @@ def _c(t):
 
 
 # ------------------------------------------------------------------------------------------------- weight packs
-_pack_cache: dict = {}
 _pack_epoch = [0]
 
 
 def invalidate_weight_cache():
     """Fused optimizers update parameters through raw pointers (no version bump): they call this."""
     _pack_epoch[0] += 1
-    if len(_pack_cache) > 4096:
-        _pack_cache.clear()
 
 
 def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
-    """Pack an fp32 parameter for the implicit-GEMM kernels (cached per parameter version)."""
-    key = (w.data_ptr(), kind, dtype, Bp)
-    tag = (w._version, _pack_epoch[0], tuple(w.shape))
-    hit = _pack_cache.get(key)
+    """Pack an fp32 parameter for the implicit-GEMM kernels.  The pack is cached ON the parameter object
+    (so it dies with it) and is refreshed whenever the parameter's version / storage / epoch changes."""
+    cache = w.__dict__.setdefault("_xr_pack", {})
+    key = (kind, dtype, Bp)
+    tag = (w._version, w.data_ptr(), _pack_epoch[0], tuple(w.shape))
+    hit = cache.get(key)
     if hit is not None and hit[0] == tag:
-        return hit[1], hit[2], hit[3]
+        return hit[1], hit[2]
     kg = kg_of(taps, Bp)
     rows = A1 * A2
-    hi = torch.empty((rows, kg), dtype=torch.bfloat16, device=w.device)
-    lo = torch.empty((rows, kg), dtype=torch.bfloat16, device=w.device) if dtype == torch.float32 else None
+    planes = 3 if dtype == torch.float32 else 1
+    pk = torch.empty((planes, rows, kg), dtype=torch.bfloat16, device=w.device)
     wd = w.detach()
     if wd.dtype != torch.float32 or not wd.is_contiguous():
         wd = wd.float().contiguous()
-    lib.xr_pack_weight(ptr(wd), ptr(hi), ptr(lo), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, stream())
-    _pack_cache[key] = (tag, hi, lo, kg)
-    return hi, lo, kg
+    lib.xr_pack_weight(ptr(wd), ptr(pk), planes, A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, stream())
+    cache[key] = (tag, pk, kg)
+    return pk, kg
 
 
 def _wgrad_split(M, K, kg):
@@ -175,11 +174,11 @@ class _Conv2d(Function):
         K, C, R, S = w.shape
         assert r8(C) == Cp, f"conv: input pitch {Cp} does not match weight C={C}"
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        hi, lo, kg = _packed(w, "fwd", x.dtype, K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
+        pk, kg = _packed(w, "fwd", x.dtype, K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         Kp = r8(K)
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(hi), ptr(lo), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
                           kg, Kp, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
@@ -197,9 +196,9 @@ class _Conv2d(Function):
         _, Ho, Wo, Kp = dy.shape
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            hi, lo, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
+            pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
-            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(hi), ptr(lo), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
+            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
                               kg, Cp, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
@@ -225,11 +224,11 @@ class _ConvTranspose2d(Function):
         Ho, Wo = (H - 1) * stride - 2 * pad + R + out_pad, (W - 1) * stride - 2 * pad + S + out_pad
         assert (Ho + 2 * pad - R) // stride + 1 == H and (Wo + 2 * pad - S) // stride + 1 == W, \
             "deconv geometry not expressible as the transposed gather"
-        hi, lo, kg = _packed(w, "tfwd", x.dtype, Cout, 1, R * S, Cin, Cp, R * S, 0, 1, Cout * R * S)
+        pk, kg = _packed(w, "tfwd", x.dtype, Cout, 1, R * S, Cin, Cp, R * S, 0, 1, Cout * R * S)
         Kp = r8(Cout)
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(hi), ptr(lo), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
                           kg, Kp, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
@@ -248,9 +247,9 @@ class _ConvTranspose2d(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # dx[n,hi,wi,ci] = sum dy[n, hi*s - p + r, ., co] w[ci][co][r][s]: an ordinary strided conv over dy
-            hi, lo, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
+            pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
-            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(hi), ptr(lo), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
+            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
                               kg, Cp, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
@@ -276,11 +275,11 @@ class _LinearNHWC(Function):
         K, F = w.shape
         assert F == C * H * W, f"linear: in_features {F} != {C}*{H}*{W}"
         HW = H * W
-        hi, lo, kg = _packed(w, "lin_fwd", x.dtype, K, 1, HW, C, C, C * HW, 0, 1, HW)
+        pk, kg = _packed(w, "lin_fwd", x.dtype, K, 1, HW, C, C, C * HW, 0, 1, HW)
         Kp = r8(K)
         y = torch.empty((N, 1, 1, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(hi), ptr(lo), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, stream())
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -297,9 +296,9 @@ class _LinearNHWC(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             # plain GEMM dx[n][p*C + c] = sum_k dy[n][k] w[k][c*HW + p]: a 1x1 "conv" with HW*C output channels
-            hi, lo, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
+            pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
-            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(hi), ptr(lo), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
+            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
                               HW * C, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
@@ -634,7 +633,7 @@ def _same_layout(a, b):
         a, b = a.float(), b.float()
     if a.dtype not in (torch.float32, torch.bfloat16):
         a, b = a.float(), b.float()
-    if a.stride() == b.stride() and a.is_non_overlapping_and_dense():
+    if a.stride() == b.stride() and (a.is_contiguous() or (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last))):
         return a, b
     return a.contiguous(), b.contiguous()
 

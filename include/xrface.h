@@ -12,8 +12,10 @@
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch allocator); the library
  *     never allocates or frees device memory and keeps no mutable global state;
  *   - activations are NHWC ("channels_last"): [N][H][W][C], C innermost;
- *   - dtype: XR_BF16 (bf16 storage, fp32 accumulate on MFMA) or XR_F32 (fp32 storage; the matrix
- *     products run as 3-term split-bf16 MFMA with fp32 accumulate, ~2^-16 relative per product);
+ *   - dtype: XR_BF16 (bf16 storage, fp32 accumulate on MFMA) or XR_F32 (fp32 storage; each operand is
+ *     split into three bf16 planes that together carry all 24 significand bits and the matrix products
+ *     run as the six plane-pair MFMAs with fp32 accumulate -- fp32-level accuracy at 6/16 of the
+ *     native fp32-MFMA cost);
  *   - stream: hipStream_t passed as void*; work is enqueued on it and never synchronised;
  *   - return: 0 on success, negative XR_E_* otherwise; xr_last_error() gives a thread-local
  *     message.  No C++ exception crosses the boundary.  All entry points are re-entrant.
@@ -51,8 +53,9 @@ int xr_device_cus(void);
  * Linear [K][C*H*W], model_irse.py:147).  Before a step the host packs them for the implicit-GEMM
  * kernels:   dst[a][t*Bp + b] = src[a1*sa1 + a2*sa2 + t*st + b*sb],  a = a1*A2 + a2,
  * rows padded with zeros to Kg (multiple of 64), b padded to Bp (multiple of 8).
- * dst_lo == NULL -> single bf16 plane; otherwise (hi, lo) split planes for XR_F32 mode. */
-int xr_pack_weight(const float* src, void* dst_hi, void* dst_lo, int A1, int A2, int taps, int B, int Bp, int Kg,
+ * nplanes = 1 (XR_BF16) or 3 (XR_F32: w = p0 + p1 + p2, each bf16, together all 24 significand bits);
+ * dst holds the planes back to back: [nplanes][A1*A2][Kg] bf16. */
+int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int taps, int B, int Bp, int Kg,
                    int64_t sa1, int64_t sa2, int64_t st, int64_t sb, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -65,7 +68,7 @@ int xr_pack_weight(const float* src, void* dst_hi, void* dst_lo, int A1, int A2,
  *   transposed == 1:  hi = (ho + pad - r)/stride when divisible     (conv dgrad / deconv forward)
  * in: [N][H][W][C] (C % 8 == 0), out: [N][Ho][Wo][K] with row pitch ldo (elements) at channel
  * offset 0 of the caller's pointer (lets producers write into a concat buffer). */
-int xr_conv_igemm(int dtype, const void* in, const void* w_hi, const void* w_lo, const float* bias, void* out,
+int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                   int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                   int transposed, int Kg, int ldo, void* stream);
 

@@ -166,8 +166,8 @@ def main():
     irse = ref_import("SUPER_RESOLUTION.model.model_irse")
     gdc = ref_import("SUPER_RESOLUTION.model.GroupDepthConv")
     st = {}
-    x = G.synth_faces(4, 112, seed=1, start=100)
-    tgt = G.synth_labels(4, 512, seed=2)
+    x = G.synth_faces(8, 112, seed=1, start=100)
+    tgt = G.synth_labels(8, 512, seed=2)
     for tag, ctor, se in (("ir50", irse.IR_50, False), ("irse50", irse.IR_SE_50, True)):
         net = ctor([112, 112])
         sd = load_det(net)
@@ -208,15 +208,15 @@ def main():
     # ------------------------------------------------------------------ ResNet-34 + KD step (a12, a18)
     resnet = ref_import("model.resnet")
     st = {}
-    x = G.synth_faces(2, 112, seed=1, start=200)
+    x = G.synth_faces(8, 112, seed=1, start=200)
     teacher = irse.IR_50([112, 112]); t_sd = load_det(teacher, 0); teacher.eval()
     student = resnet.ResNet_34(); s_sd = load_det(student, 1)
     assistant = resnet.ResNet_34(); a_sd = load_det(assistant, 2)
     keys["resnet34"] = {k: list(v.shape) for k, v in student.state_dict().items()}
     student.eval()
     with torch.no_grad():
-        ref_out = student(x)
-        mine = R.resnet34(s_sd, x, train=False)
+        ref_out = student(x[:2])
+        mine = R.resnet34(s_sd, x[:2], train=False)
     for i, nm in enumerate(("emb", "x1", "x2", "x3", "x4")):
         close(mine[i], ref_out[i], f"resnet34 eval {nm}")
         pack(st, f"r34/eval/{nm}", ref_out[i])

@@ -17,3 +17,26 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Print (and save) the measured parity errors so DESIGN.md can quote them."""
+    try:
+        from tests.helpers import ERRORS
+    except Exception:
+        return
+    if not ERRORS:
+        return
+    worst = {}
+    for what, e, tol in ERRORS:
+        if what not in worst or not (e <= worst[what][0]):
+            worst[what] = (e, tol)
+    rows = sorted(worst.items(), key=lambda kv: -(kv[1][0] / kv[1][1] if kv[1][0] == kv[1][0] else 9e9))
+    terminalreporter.write_line("parity errors (measured / tolerance), worst first:")
+    for what, (e, tol) in rows[:25]:
+        terminalreporter.write_line(f"  {what:60s} {e:.3e} / {tol:.1e}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "parity_errors.json"), "w") as f:
+            json.dump({k: {"err": v[0], "tol": v[1]} for k, v in worst.items()}, f, indent=1)

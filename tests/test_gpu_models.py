@@ -1,0 +1,222 @@
+"""GPU: model-level parity of the HIP path against the CPU oracle (oracle/cpu_ref.py) and the golden
+fixtures generated from the reference.  North-star tolerance: 1e-3 relative fp32 (BASELINE.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as R
+from oracle import detgen as G
+from tests.helpers import GOLD, check_against, grad_floor, load_gold, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 1e-3       # forward outputs: SR images, heat-maps, embeddings, losses (north_star)
+# Parameter gradients after 50-100 layers of backprop through small-batch train-mode Batch/InstanceNorm are
+# ill-conditioned: the HIP path's own run-to-run spread (fp32 atomic summation order in the statistics, ~1e-7
+# relative) already moves first-layer gradients by up to ~5e-3 of their max-abs, so they are held to 1e-2
+# (3e-2 for the 2 x ResNet-34 + IR-50 KD chain); forward outputs and losses are held to the north-star 1e-3.
+GRAD_TOL = 1e-2
+KD_GRAD_TOL = 3e-2
+
+
+def load_det(module, seed=0):
+    sd = G.det_state_dict(module.state_dict(), seed)
+    module.load_state_dict(sd)
+    return module.to(DEV), sd
+
+
+def grads_by_name(module):
+    return {k: p.grad for k, p in module.named_parameters()}
+
+
+def test_coarse_c1_step_matches_oracle_and_fixture():
+    """BASELINE config 1: Course_SR_Network fwd + bwd of 12*mse97 (N=2 here, the fixture's batch)."""
+    import xrface
+    from xrface.loss.loss import MSELossFunc
+    from xrface.model.FSRnet import Course_SR_Network
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("fsrnet_root.npz")
+    net, sd = load_det(Course_SR_Network())
+    hr = G.synth_faces(2, 112, seed=1)
+    lr = G.synth_lr_from_hr(hr)
+    feat, img = net(lr.to(DEV))
+    assert feat.shape == (2, 64, 112, 112) and img.shape == (2, 3, 112, 112)
+    check_against(st, "coarse/feat", feat, TOL)
+    check_against(st, "coarse/img", img, TOL)
+    loss = 12.0 * MSELossFunc()(img, hr.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(st["c1/loss"])) <= TOL * abs(float(st["c1/loss"]))
+    g = grads_by_name(net)
+    l_ref, _, g_ref = R.coarse_step_grads(sd, lr, hr)
+    gscale = max(float(v.abs().max()) for v in g_ref.values() if v is not None)
+    for k, gr in g_ref.items():
+        if gr is None:
+            assert g[k] is None, f"{k} must keep .grad None (stock optimizers skip it)"
+            continue
+        err = float((g[k].cpu().double() - gr.double()).abs().max()) / max(float(gr.abs().max()), 1e-2 * gscale)
+        assert err < 2 * TOL, (k, err)
+    for k in ("conv_input.weight", "conv_mid.weight", "bn_mid.weight", "relu.weight", "residual.1.conv2.weight",
+              "residual.0.relu_out.weight", "residual.2.in1.weight"):
+        check_against(st, "c1/grad/" + k, g[k], 2 * TOL)
+
+
+def test_fhn_modules_forward():
+    import xrface
+    from xrface.model import FSRnet
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("fsrnet_root.npz")
+    hr = G.synth_faces(2, 112, seed=1).to(DEV)
+    enc, _ = load_det(FSRnet.Fine_SR_Encoder())
+    e = enc(hr)
+    check_against(st, "encoder/out", e, TOL)
+    prior, _ = load_det(FSRnet.Prior_Estimation_Network())
+    pf, lmk, par = prior(hr)
+    assert lmk.shape == (2, 97, 28, 28) and par.shape == (2, 11, 28, 28)
+    check_against(st, "prior/feat", pf, TOL)
+    check_against(st, "prior/landmark", lmk, TOL)
+    check_against(st, "prior/parsing", par, TOL)
+    dec, _ = load_det(FSRnet.Fine_SR_Decoder())
+    out = dec(torch.cat((pf, e), 1))
+    check_against(st, "decoder/out", out, TOL)
+
+
+def test_fhn_step_per_pair_gradients():
+    """One forward, per-(loss_k, theta_k) gradients at pre-step weights."""
+    import xrface
+    from xrface.steps import fhn_step
+    from xrface.model import FSRnet
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("fsrnet_root.npz")
+    nets = {}
+    for k, ctor in (("coarse", FSRnet.Course_SR_Network), ("encoder", FSRnet.Fine_SR_Encoder),
+                    ("prior", FSRnet.Prior_Estimation_Network), ("decoder", FSRnet.Fine_SR_Decoder)):
+        nets[k], _ = load_det(ctor())
+    hr = G.synth_faces(2, 112, seed=1)
+    lr = G.synth_lr_from_hr(hr)
+    hm = G.synth_heatmap(2, 28, 97, 1.3, seed=2)
+    par = G.synth_parsing(2, 28, 11, seed=2)
+    losses, outs = fhn_step(nets, lr.to(DEV), hr.to(DEV), hm.to(DEV), par.to(DEV))
+    check_against(st, "fhn/sr", outs["sr"], TOL)
+    check_against(st, "fhn/landmark", outs["landmark"], TOL)
+    for k in ("coarse", "encoder", "prior", "decoder"):
+        ref = float(st[f"fhn/loss/{k}"])
+        assert abs(losses[k].item() - ref) <= TOL * abs(ref), (k, losses[k].item(), ref)
+        none_ref = set(st[f"fhn/{k}/none_grad_keys"].tolist())
+        got_none = {n for n, p in nets[k].named_parameters() if p.grad is None}
+        assert got_none == none_ref, (k, got_none ^ none_ref)
+        for key in st.files:
+            pre = f"fhn/{k}/grad/"
+            if key.startswith(pre):
+                name = key[len(pre):].replace("@digest", "")
+                check_against(st, pre + name, dict(nets[k].named_parameters())[name].grad, GRAD_TOL,
+                              floor=grad_floor(st, pre))
+
+
+@pytest.mark.parametrize("tag,se", [("ir50", False), ("irse50", True)])
+def test_ir_backbone_eval_and_train(tag, se):
+    import xrface
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model import model_irse
+    from xrface.model.GroupDepthConv import FeatureExtractor
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("irse.npz")
+    net, sd = load_det((model_irse.IR_SE_50 if se else model_irse.IR_50)([112, 112]))
+    x = G.synth_faces(8, 112, seed=1, start=100)
+    tgt = G.synth_labels(8, 512, seed=2)
+    net.eval()
+    with torch.no_grad():
+        emb = net(x[:2].to(DEV))
+        feats, _, last, _ = FeatureExtractor()(net.input_layer(x[:2].to(DEV)), ["2", "6", "20", "21", "22", "23"], net.body)
+    check_against(st, f"{tag}/eval/emb", emb, TOL)
+    e_rel = float((emb.cpu() - torch.from_numpy(st[f"{tag}/eval/emb"])).norm(dim=1).max() /
+                  torch.from_numpy(st[f"{tag}/eval/emb"]).norm(dim=1).min())
+    assert e_rel < TOL, f"embedding L2 error {e_rel:.2e}"
+    for k in ("2", "6", "20", "21", "22", "23"):
+        check_against(st, f"{tag}/eval/tap{k}", feats[k], TOL)
+    # train step, Dropout pinned off (p = 0) exactly like the fixture
+    net.train()
+    net.output_layer[1].p = 0.0
+    out = net(x.to(DEV))
+    loss = CrossEntropyLoss()(out, tgt.to(DEV))
+    loss.backward()
+    check_against(st, f"{tag}/train/emb", out, TOL)
+    assert abs(loss.item() - float(st[f"{tag}/train/loss"])) <= TOL * abs(float(st[f"{tag}/train/loss"]))
+    g = grads_by_name(net)
+    floor = grad_floor(st, f"{tag}/train/grad/")
+    for key in st.files:
+        pre = f"{tag}/train/grad/"
+        if key.startswith(pre):
+            name = key[len(pre):].replace("@digest", "")
+            check_against(st, pre + name, g[name], GRAD_TOL, floor=floor)
+    new_sd = net.state_dict()
+    for k in ("input_layer.1.running_mean", "input_layer.1.running_var", "body.23.res_layer.4.running_var",
+              "output_layer.4.running_mean"):
+        check_against(st, f"{tag}/train/stats/{k}", new_sd[k], TOL)
+    assert int(new_sd["input_layer.1.num_batches_tracked"]) == 1
+
+
+def test_ir_dropout_mask_matches_oracle():
+    import xrface
+    from xrface.model import model_irse
+    xrface.set_compute_dtype(torch.float32)
+    net, sd = load_det(model_irse.IR_50([112, 112]))
+    x = G.synth_faces(4, 112, seed=1, start=300)
+    mask_nchw = (torch.from_numpy(G.uniform01("mask", 4 * 512 * 49).reshape(4, 512, 7, 7)) < 0.5)
+    net.train()
+    net.output_layer[1].inject_mask = mask_nchw.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = net(x.to(DEV))
+    ref, _ = R.ir_backbone(sd, x, se=False, train=True, drop_mask=mask_nchw.float())
+    assert rel_err(out, ref) < TOL
+
+
+def test_resnet34_and_kd_step():
+    import xrface
+    from xrface.model import model_irse, resnet
+    from xrface.steps import kd_step
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("resnet_kd.npz")
+    x = G.synth_faces(8, 112, seed=1, start=200)
+    teacher, _ = load_det(model_irse.IR_50([112, 112]), 0)
+    student, _ = load_det(resnet.ResNet_34(), 1)
+    assistant, _ = load_det(resnet.ResNet_34(), 2)
+    student.eval()
+    with torch.no_grad():
+        out = student(x[:2].to(DEV))
+    for i, nm in enumerate(("emb", "x1", "x2", "x3", "x4")):
+        check_against(st, f"r34/eval/{nm}", out[i], TOL)
+    (sl, al), s_out, a_out, t_out = kd_step(teacher, student, assistant, x.to(DEV))
+    assert abs(sl.item() - float(st["kd/student_loss"])) <= TOL * abs(float(st["kd/student_loss"]))
+    assert abs(al.item() - float(st["kd/assistant_loss"])) <= TOL * abs(float(st["kd/assistant_loss"]))
+    check_against(st, "kd/t_emb", t_out[0], TOL)
+    check_against(st, "kd/s_emb", s_out[0], TOL)
+    for who, net in (("student", student), ("assistant", assistant)):
+        g = grads_by_name(net)
+        for key in st.files:
+            pre = f"kd/{who}/grad/"
+            if key.startswith(pre):
+                name = key[len(pre):].replace("@digest", "")
+                check_against(st, pre + name, g[name], KD_GRAD_TOL, floor=grad_floor(st, pre))
+
+
+def test_bf16_throughput_mode_embedding_error_is_reported():
+    """bf16 mode is the throughput path; its embedding error versus the fp32 fixture is bounded loosely
+    (bf16 has ~3 significant digits) and printed for DESIGN.md."""
+    import xrface
+    from xrface.model import model_irse
+    st = load_gold("irse.npz")
+    net, _ = load_det(model_irse.IR_SE_50([112, 112]))
+    net.eval()
+    x = G.synth_faces(2, 112, seed=1, start=100)
+    xrface.set_compute_dtype(torch.bfloat16)
+    try:
+        with torch.no_grad():
+            emb = net(x.to(DEV)).float()
+    finally:
+        xrface.set_compute_dtype(torch.float32)
+    ref = torch.from_numpy(st["irse50/eval/emb"])
+    err = float((emb.cpu() - ref).norm(dim=1).max() / ref.norm(dim=1).min())
+    print(f"[bf16] IR-SE-50 embedding relative L2 error vs fp32 reference: {err:.3e}")
+    assert err < 0.1

@@ -1,0 +1,355 @@
+"""GPU: every HIP op against a plain PyTorch fp32 CPU reference of the same op, through the C ABI.
+Tolerances: XR_F32 mode (split-bf16 MFMA, fp32 accumulate) 2e-4 relative to max-abs -- well inside the
+1e-3 of BASELINE.json's north_star; XR_BF16 mode 2e-2 (bf16 has 8 significant bits)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen as G
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
+
+
+def rnd(key, *shape, scale=1.0):
+    return torch.from_numpy((G.normal(key, int(np.prod(shape))) * scale).reshape(shape).astype(np.float32))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+def to_buf(x_nchw, dtype):
+    from xrface import ops
+    return ops.enter(x_nchw.to(DEV), dtype)
+
+
+def from_buf(buf, C):
+    return buf.float().permute(0, 3, 1, 2)[:, :C].cpu()
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad, bias
+    (2, 64, 20, 20, 64, 3, 1, 1, False),
+    (2, 3, 24, 24, 64, 3, 1, 1, True),
+    (1, 64, 14, 14, 3, 3, 1, 1, True),
+    (2, 64, 28, 28, 128, 3, 2, 1, False),
+    (3, 128, 9, 9, 128, 3, 1, 1, False),
+    (2, 3, 56, 56, 128, 7, 4, 3, True),
+    (2, 3, 40, 40, 64, 7, 2, 3, False),
+    (2, 64, 16, 16, 128, 1, 2, 0, False),
+    (2, 128, 7, 7, 97, 1, 1, 0, True),
+    (1, 192, 12, 12, 64, 3, 1, 1, True),
+    (2, 256, 7, 7, 512, 3, 2, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case, dtype):
+    from xrface import ops
+    N, C, H, W, K, R, stride, pad, bias = case
+    x = rnd(f"cx{case}", N, C, H, W)
+    w = rnd(f"cw{case}", K, C, R, R, scale=(C * R * R) ** -0.5)
+    b = rnd(f"cb{case}", K, scale=0.1) if bias else None
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    y_ref = F.conv2d(xr, wr, br, stride, pad)
+    gy = rnd(f"cg{case}", *y_ref.shape)
+    y_ref.backward(gy)
+
+    xg = x.to(DEV).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = b.to(DEV).requires_grad_(True) if bias else None
+    buf = ops.enter(xg, dtype)
+    yb = ops.conv2d(buf, wg, bg, stride, pad)
+    assert yb.shape == (N, y_ref.shape[2], y_ref.shape[3], ops.r8(K))
+    if ops.r8(K) != K:
+        assert float(yb[..., K:].abs().max()) == 0.0, "channel padding must be zero"
+    y = ops.leave(yb, K)
+    tol = TOL[dtype]
+    assert rel(y, y_ref) < tol
+    y.backward(gy.to(DEV))
+    assert rel(xg.grad, xr.grad) < tol
+    assert rel(wg.grad, wr.grad) < tol
+    if bias:
+        assert rel(bg.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_transpose2d_k7s4(dtype):
+    from xrface import ops
+    N, Cin, Cout, H = 2, 64, 64, 7
+    x = rnd("dx", N, Cin, H, H)
+    w = rnd("dw", Cin, Cout, 7, 7, scale=0.05)
+    b = rnd("db", Cout, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.conv_transpose2d(xr, wr, br, stride=4, padding=2, output_padding=1)
+    gy = rnd("dg", *y_ref.shape)
+    y_ref.backward(gy)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.leave(ops.conv_transpose2d(ops.enter(xg, dtype), wg, bg, 4, 2, 1), Cout)
+    assert y.shape == y_ref.shape
+    tol = TOL[dtype]
+    assert rel(y, y_ref) < tol
+    y.backward(gy.to(DEV))
+    assert rel(xg.grad, xr.grad) < tol
+    assert rel(wg.grad, wr.grad) < tol
+    assert rel(bg.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_flatten_order(dtype):
+    from xrface import ops
+    N, C, H, K = 5, 64, 7, 512
+    x = rnd("lx", N, C, H, H)
+    w = rnd("lw", K, C * H * H, scale=(C * H * H) ** -0.5)
+    b = rnd("lb", K, scale=0.1)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    y_ref = F.linear(xr.flatten(1), wr, br)
+    gy = rnd("lg", N, K)
+    y_ref.backward(gy)
+    xg, wg, bg = (t.to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.leave2d(ops.linear_nhwc(ops.enter(xg, dtype), wg, bg))
+    tol = TOL[dtype]
+    assert rel(y, y_ref) < tol
+    y.backward(gy.to(DEV).to(y.dtype))
+    assert rel(xg.grad, xr.grad) < tol
+    assert rel(wg.grad, wr.grad) < tol
+    assert rel(bg.grad, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode,act,with_res", [("in", "prelu", True), ("in", None, False), ("bn", "relu", True),
+                                               ("bn", "prelu", False), ("bn_eval", None, True), ("none", "prelu", False),
+                                               ("in_noaffine", "prelu", True)])
+def test_norm_act(mode, act, with_res, dtype):
+    from xrface import ops
+    N, C, H, W = 3, 64, 10, 12
+    x = rnd("nx" + mode, N, C, H, W) * 1.5 + 0.3
+    res = rnd("nr" + mode, N, C, H, W) if with_res else None
+    gamma, beta = rnd("ng", C) * 0.3 + 1.0, rnd("nb", C) * 0.2
+    alpha = rnd("na", C) * 0.1 + 0.3
+    rm, rv = rnd("nm", C) * 0.1, rnd("nv", C).abs() + 0.5
+    if dtype == torch.bfloat16:  # compare on the same bf16-rounded inputs
+        x, res = x.bfloat16().float(), (res.bfloat16().float() if with_res else None)
+    leaves = [t.clone().requires_grad_(True) for t in (x, gamma, beta, alpha)]
+    xr, gr, br, ar = leaves
+    rr = res.clone().requires_grad_(True) if with_res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    if mode == "in":
+        z = F.instance_norm(xr, None, None, gr, br, True, 0.0, 1e-5)
+    elif mode == "in_noaffine":
+        z = F.instance_norm(xr, None, None, None, None, True, 0.0, 1e-5)
+    elif mode == "bn":
+        z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    elif mode == "bn_eval":
+        z = F.batch_norm(xr, rm_ref, rv_ref, gr, br, False, 0.1, 1e-5)
+    else:
+        z = xr
+    if with_res:
+        z = z + rr
+    y_ref = F.prelu(z, ar) if act == "prelu" else (F.relu(z) if act == "relu" else z)
+    gy = rnd("ngy" + mode, N, C, H, W)
+    y_ref.backward(gy)
+
+    xg, gg, bg, ag = (t.detach().clone().to(DEV).requires_grad_(True) for t in (x, gamma, beta, alpha))
+    rg = res.to(DEV).requires_grad_(True) if with_res else None
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    buf = ops.enter(xg, dtype)
+    rbuf = ops.enter(rg, dtype) if with_res else None
+    kind = {"in": "in", "in_noaffine": "in", "bn": "bn", "bn_eval": "bn", "none": "none"}[mode]
+    affine = mode in ("in", "bn", "bn_eval")
+    yb = ops.norm_act(buf, gg if affine else None, bg if affine else None, rmg if kind == "bn" else None,
+                      rvg if kind == "bn" else None, rbuf, ag if act == "prelu" else None, kind, act,
+                      training=(mode != "bn_eval"))
+    y = ops.leave(yb)
+    tol = TOL[dtype]
+    assert rel(y, y_ref) < tol
+    y.backward(gy.to(DEV).to(y.dtype))
+    gtol = tol * 3
+    assert rel(xg.grad, xr.grad) < gtol
+    if with_res:
+        assert rel(rg.grad, rr.grad) < gtol
+    if affine:
+        assert rel(gg.grad, gr.grad) < gtol
+        assert rel(bg.grad, br.grad) < gtol
+    if act == "prelu":
+        assert rel(ag.grad, ar.grad) < gtol
+    if mode == "bn":
+        assert rel(rmg, rm_ref) < 1e-4 and rel(rvg, rv_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_se_scale_add(dtype):
+    from xrface import ops
+    N, C, H = 3, 64, 9
+    r = rnd("ser", N, C, H, H)
+    sc = rnd("ses", N, C, H, H)
+    w1 = rnd("sew1", C // 16, C, 1, 1, scale=0.3)
+    w2 = rnd("sew2", C, C // 16, 1, 1, scale=0.5)
+    if dtype == torch.bfloat16:
+        r, sc = r.bfloat16().float(), sc.bfloat16().float()
+    rr, sr, w1r, w2r = (t.clone().requires_grad_(True) for t in (r, sc, w1, w2))
+    s = torch.sigmoid(F.conv2d(F.relu(F.conv2d(rr.mean((2, 3), keepdim=True), w1r)), w2r))
+    y_ref = rr * s + sr
+    gy = rnd("seg", N, C, H, H)
+    y_ref.backward(gy)
+    rg, sg, w1g, w2g = (t.to(DEV).requires_grad_(True) for t in (r, sc, w1, w2))
+    y = ops.leave(ops.se_scale_add(ops.enter(rg, dtype), w1g, w2g, ops.enter(sg, dtype)))
+    tol = TOL[dtype]
+    assert rel(y, y_ref) < tol
+    y.backward(gy.to(DEV).to(y.dtype))
+    for a, b in ((rg, rr), (sg, sr), (w1g, w1r), (w2g, w2r)):
+        assert rel(a.grad, b.grad) < 3 * tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_resampling_ops(dtype):
+    from xrface import ops
+    N, C, H = 2, 128, 12
+    x = rnd("rsx", N, C, H, H)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    # subsample == MaxPool2d(1, 2)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 1, 2)
+    gy = rnd("rsg", *y_ref.shape)
+    y_ref.backward(gy)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.leave(ops.subsample(ops.enter(xg, dtype), 2))
+    assert rel(y, y_ref) < 1e-6
+    y.backward(gy.to(DEV).to(y.dtype))
+    assert rel(xg.grad, xr.grad) < TOL[dtype]
+    # maxpool 2x2
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 2, 2)
+    gy = rnd("rsg2", *y_ref.shape)
+    y_ref.backward(gy)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.leave(ops.maxpool2(ops.enter(xg, dtype)))
+    assert rel(y, y_ref) < 1e-6
+    y.backward(gy.to(DEV).to(y.dtype))
+    assert rel(xg.grad, xr.grad) < TOL[dtype]
+    # up1 + nearest-up(low)
+    low = rnd("rsl", N, C, H // 2, H // 2)
+    if dtype == torch.bfloat16:
+        low = low.bfloat16().float()
+    xr, lr_ = x.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    y_ref = xr + F.interpolate(lr_, scale_factor=2)
+    gy = rnd("rsg3", *y_ref.shape)
+    y_ref.backward(gy)
+    xg, lg = x.to(DEV).requires_grad_(True), low.to(DEV).requires_grad_(True)
+    y = ops.leave(ops.upadd2(ops.enter(xg, dtype), ops.enter(lg, dtype)))
+    assert rel(y, y_ref) < TOL[dtype]
+    y.backward(gy.to(DEV).to(y.dtype))
+    assert rel(xg.grad, xr.grad) < TOL[dtype] and rel(lg.grad, lr_.grad) < TOL[dtype]
+    # cat
+    a, b = rnd("cata", N, 128, 6, 6), rnd("catb", N, 64, 6, 6)
+    ag, bg = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.leave(ops.cat2(ops.enter(ag, torch.float32), ops.enter(bg, torch.float32)))
+    assert rel(y, torch.cat((a, b), 1)) < 1e-7
+    gy = rnd("catg", N, 192, 6, 6)
+    y.backward(gy.to(DEV))
+    assert rel(ag.grad, gy[:, :128]) < 1e-7 and rel(bg.grad, gy[:, 128:]) < 1e-7
+
+
+def test_dropout_mask_and_stream():
+    from xrface import ops
+    x = rnd("dox", 4, 512, 7, 7).to(DEV).requires_grad_(True)
+    buf = ops.enter(x, torch.float32)
+    mask = (torch.from_numpy(G.uniform01("dom", buf.numel()).reshape(buf.shape)) < 0.5).to(DEV)
+    y = ops.dropout(buf, 0.5, True, mask=mask)
+    assert rel(y, buf.detach() * mask * 2.0) < 1e-7
+    y.sum().backward()
+    assert rel(x.grad.permute(0, 2, 3, 1), mask.float() * 2.0) < 1e-7
+    y2 = ops.dropout(buf.detach(), 0.5, True, seed=123)
+    keep = float((y2 != 0).float().mean())
+    assert 0.47 < keep < 0.53
+    assert torch.equal(y2, ops.dropout(buf.detach(), 0.5, True, seed=123))
+    assert ops.dropout(buf, 0.5, False) is buf
+
+
+def test_losses_against_reference_fixture():
+    """Inputs/targets/expected values come from the reference's own loss modules (tests/golden/losses.npz)."""
+    from tests.helpers import load_gold
+    from xrface.loss.loss import CrossEntropyLoss2d, MSELoss_Landmark, MSELossFunc
+    st = load_gold("losses.npz")
+    for nm, mod in (("mse97", MSELossFunc()), ("landmark", MSELoss_Landmark()), ("nll2d", CrossEntropyLoss2d())):
+        x = torch.from_numpy(st[nm + "/in"]).to(DEV).requires_grad_(True)
+        t = torch.from_numpy(st[nm + "/target"]).to(DEV)
+        loss = mod(x, t)
+        (loss * 1.7).backward()
+        assert abs(loss.item() - float(st[nm + "/loss"])) <= 1e-4 * abs(float(st[nm + "/loss"])), nm
+        assert rel(x.grad, torch.from_numpy(st[nm + "/grad"]) * 1.7) < 1e-4, nm
+
+
+def test_cross_entropy_rows():
+    from xrface import ops
+    x = rnd("cex", 16, 512)
+    t = G.synth_labels(16, 512)
+    xr = x.clone().requires_grad_(True)
+    l_ref = F.cross_entropy(xr, t)
+    l_ref.backward()
+    xg = x.to(DEV).requires_grad_(True)
+    l = ops.cross_entropy(xg, t.to(DEV))
+    l.backward()
+    assert abs(l.item() - l_ref.item()) < 1e-5 * abs(l_ref.item())
+    assert rel(xg.grad, xr.grad) < 1e-4
+
+
+def test_fused_optimizers_match_torch_optim():
+    from xrface._lib import lib, ptr, stream
+    n = 10007
+    p0, g = rnd("opp", n), rnd("opg", n)
+    for kind in ("sgd", "rmsprop", "adam"):
+        pr = p0.clone().requires_grad_(True)
+        if kind == "sgd":
+            opt = torch.optim.SGD([pr], lr=0.1, momentum=0.9, weight_decay=1e-3)
+        elif kind == "rmsprop":
+            opt = torch.optim.RMSprop([pr], lr=5e-3, alpha=0.99, weight_decay=1e-5)
+        else:
+            opt = torch.optim.Adam([pr], lr=1e-3, betas=(0.5, 0.999), weight_decay=1e-5)
+        pg = p0.to(DEV)
+        s1, s2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for step in range(1, 4):
+            pr.grad = g * step
+            opt.step()
+            gg = (g * step).to(DEV)
+            if kind == "sgd":
+                lib.xr_sgd_step(ptr(pg), ptr(gg), ptr(s1), n, 0.1, 0.9, 1e-3, None, int(step == 1), stream())
+            elif kind == "rmsprop":
+                lib.xr_rmsprop_step(ptr(pg), ptr(gg), ptr(s1), n, 5e-3, 0.99, 1e-8, 1e-5, stream())
+            else:
+                lib.xr_adam_step(ptr(pg), ptr(gg), ptr(s1), ptr(s2), n, 1e-3, 0.5, 0.999, 1e-8, 1e-5, step, stream())
+        assert rel(pg, pr) < 2e-6, kind
+
+
+def test_pairdist_and_roc_against_reference_fixture():
+    """dist vs the reference's numpy value (fp32 summation order differs: 1e-6 rel); the threshold sweep is
+    integer-exact on a given dist array, and the whole calculate_roc matches the reference fixture."""
+    from tests.helpers import load_gold
+    from xrface.utils.utils import calculate_roc, pair_dist, roc_histograms
+    from oracle import cpu_ref as R
+    st = load_gold("roc.npz")
+    p = int(st["p"])
+    e1, e2, same = G.synth_pairs(p, 512, seed=0)
+    dist = pair_dist(e1, e2).cpu().numpy()
+    assert np.abs(dist - st["dist"]).max() / st["dist"].max() < 2e-6
+    thresholds = np.arange(0, 12000, 3)
+    hist = roc_histograms(torch.from_numpy(st["dist"]).to(DEV), same, st["fold_id"], thresholds, 10).cpu().numpy()
+    for f in range(10):
+        sel = st["fold_id"] == f
+        tp, fp, tn, fn = R.confusion_at(thresholds, st["dist"][sel], same[sel])
+        assert np.array_equal(np.cumsum(hist[f, 1])[:-1], tp) and np.array_equal(np.cumsum(hist[f, 0])[:-1], fp)
+    tpr, fpr, acc, best = calculate_roc(thresholds, e1, e2, same, nrof_folds=10, fold_id=st["fold_id"])
+    assert np.abs(tpr - st["tpr"]).max() < 5e-3 and np.abs(fpr - st["fpr"]).max() < 5e-3
+    assert abs(acc - float(st["acc"])) < 5e-3 and np.abs(best - st["best"]).max() <= 6
+    # empty-ish / ragged edge: one pair, one threshold, one fold
+    t1, f1, a1, b1 = calculate_roc(np.array([1.0]), e1[:1], e2[:1], same[:1], nrof_folds=1, fold_id=np.zeros(1, np.int32))
+    assert t1.shape == (1,) and b1.shape == (1,)
