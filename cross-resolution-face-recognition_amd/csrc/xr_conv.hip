@@ -26,6 +26,9 @@ struct IgemmP {
   const float* bias;
   void* out;
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo, M, tiles_n;
+  int cls, tpc, Mc;   // class mode (transposed gather, stride > 1): output pixels grouped by (ho % s, wo % s)
+  float* ws;          // split-K fp32 workspace [M][ldo] (atomics) or nullptr
+  int ksplit;         // K-stages per blockIdx.y slice (split-K), 0 = no split
 };
 
 // decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
@@ -118,19 +121,54 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const int tile_n = blockIdx.x % p.tiles_n;
-  const int tile_m = blockIdx.x / p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  // XCD-aware tile order: consecutive workgroup ids are dealt round-robin over the 8 XCDs; give each XCD a
+  // contiguous run of tiles so neighbouring tiles (shared halo rows / shared weight panel) meet in one L2
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % p.tiles_n;
+  const int tile_m = bid / p.tiles_n;
+  const int n0 = tile_n * BN;
   const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
   const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
+  // class mode bookkeeping (wave-uniform)
+  const bool cls_mode = TR && p.cls;
+  int ph = 0, pw = 0, r0 = 0, s0 = 0, nr = 0, ns = 0, t_in = tile_m;
+  if (cls_mode) {
+    const int c = tile_m / p.tpc;
+    t_in = tile_m - c * p.tpc;
+    ph = c / p.stride; pw = c - ph * p.stride;
+    r0 = (ph + p.pad) % p.stride; s0 = (pw + p.pad) % p.stride;
+    nr = r0 < p.R ? (p.R - r0 + p.stride - 1) / p.stride : 0;
+    ns = s0 < p.S ? (p.S - s0 + p.stride - 1) / p.stride : 0;
+  }
+  // tile row -> output pixel (memory index m_out, or -1) and gather origin
+  auto decode_row = [&](int row, bool& valid, int& nb, int& oh0, int& ow0) -> int {
+    if (!cls_mode) {
+      const int m = tile_m * BM + row;
+      decode_pixel<TR>(m, p.M, HoWo, p.Wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
+      return valid ? m : -1;
+    }
+    const int idx = t_in * BM + row;
+    valid = idx < p.Mc;
+    const int Hq = p.Ho / p.stride, Wq = p.Wo / p.stride;
+    const int ii = valid ? idx : 0;
+    const int n = ii / (Hq * Wq);
+    const int rem = ii - n * (Hq * Wq);
+    const int hq = rem / Wq, wq = rem - hq * Wq;
+    const int ho = hq * p.stride + ph, wo = wq * p.stride + pw;
+    nb = n * HW; oh0 = ho + p.pad; ow0 = wo + p.pad;
+    return valid ? (n * p.Ho + ho) * p.Wo + wo : -1;
+  };
 
   const int cc = t & 7;   // 16-B chunk column inside the K-stage
   const int rbase = t >> 3;
   bool a_valid[RA];
   int a_nb[RA], a_oh[RA], a_ow[RA];
 #pragma unroll
-  for (int i = 0; i < RA; ++i)
-    decode_pixel<TR>(m0 + rbase + 32 * i, p.M, HoWo, p.Wo, HW, p.stride, p.pad, a_valid[i], a_nb[i], a_oh[i], a_ow[i]);
+  for (int i = 0; i < RA; ++i) (void)decode_row(rbase + 32 * i, a_valid[i], a_nb[i], a_oh[i], a_ow[i]);
 
   float a_f[MODE ? RA : 1][8];
   uint4 a_u[MODE ? 1 : RA];
@@ -138,12 +176,24 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   const int taps = p.R * p.S;
 
   auto load_stage = [&](int kk) {
-    const int k0 = kk * BK + cc * 8;
-    const int tap = k0 / p.C;
-    const int c = k0 - tap * p.C;
-    const int r = tap / p.S;
-    const int s = tap - r * p.S;
-    const bool tap_ok = tap < taps;
+    int k0, c, r, s;
+    bool tap_ok;
+    if (cls_mode) {  // only the taps this output class can see; C % 64 == 0 so a stage never straddles taps
+      const int cpt = p.C >> 6;
+      const int ti = kk / cpt;
+      c = (kk - ti * cpt) * BK + cc * 8;
+      const int ri = ti / ns, si = ti - ri * ns;
+      r = r0 + ri * p.stride; s = s0 + si * p.stride;
+      k0 = (r * p.S + s) * p.C + c;
+      tap_ok = true;
+    } else {
+      k0 = kk * BK + cc * 8;
+      const int tap = k0 / p.C;
+      c = k0 - tap * p.C;
+      r = tap / p.S;
+      s = tap - r * p.S;
+      tap_ok = tap < taps;
+    }
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       int pix = 0;
@@ -202,10 +252,15 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
 
   const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
   const int lr = lane & 31, lh = lane >> 5;
-  const int nk = p.Kg / BK;
+  int nk = cls_mode ? nr * ns * (p.C >> 6) : p.Kg / BK;
+  int kbeg = 0;
+  if (p.ksplit > 0) {
+    kbeg = blockIdx.y * p.ksplit;
+    nk = (kbeg + p.ksplit < nk) ? kbeg + p.ksplit : nk;
+  }
 
-  load_stage(0);
-  for (int kk = 0; kk < nk; ++kk) {
+  if (kbeg < nk) load_stage(kbeg);
+  for (int kk = kbeg; kk < nk; ++kk) {
     store_stage();
     __syncthreads();
     if (kk + 1 < nk) load_stage(kk + 1);
@@ -232,6 +287,21 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
     __syncthreads();
   }
 
+  if (p.ws != nullptr) {  // split-K: fp32 atomics into the workspace; bias/cast happen in xr_bias_cast
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn0 + j * 32 + lr;
+        if (col >= p.ldo) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = tile_m * BM + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m < p.M) atomicAdd(p.ws + (size_t)m * p.ldo + col, acc[i][j][e]);
+        }
+      }
+    return;
+  }
   // epilogue: accumulators (+bias) -> LDS row image -> coalesced 16-B-chunk stores
   out_t* stage = reinterpret_cast<out_t*>(smem);
   constexpr int PITCH = BN + PADE;
@@ -253,9 +323,17 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   const int Kw = (p.K + 7) & ~7;
   for (int idx = t; idx < BM * CPR; idx += NT) {
     const int row = idx / CPR, ch = idx - row * CPR;
-    const int m = m0 + row;
     const int ncol = n0 + ch * 8;
-    if (m >= p.M || ncol >= Kw) continue;  // Kw = K rounded up to 8: padding channels are written as zeros
+    if (ncol >= Kw) continue;  // Kw = K rounded up to 8: padding channels are written as zeros
+    int m;
+    if (cls_mode) {
+      bool v; int a, b, c;
+      m = decode_row(row, v, a, b, c);
+    } else {
+      m = tile_m * BM + row;
+      if (m >= p.M) m = -1;
+    }
+    if (m < 0) continue;
     const out_t* sp = stage + row * PITCH + ch * 8;
     out_t* dp = out + (size_t)m * p.ldo + ncol;
     if (ncol + 8 <= Kw) {
@@ -283,7 +361,24 @@ constexpr size_t igemm_smem() {
 template <int MODE, int BM, int BN, int WM, bool TR>
 int launch_igemm(IgemmP& p, hipStream_t st) {
   p.tiles_n = cdiv((p.K + 7) / 8 * 8, BN);
-  const int tiles_m = cdiv(p.M, BM);
+  int tiles_m = cdiv(p.M, BM);
+  p.cls = 0; p.tpc = 0; p.Mc = 0;
+  if (TR && p.stride > 1 && p.Ho % p.stride == 0 && p.Wo % p.stride == 0 && p.C % 64 == 0 && p.ws == nullptr) {
+    p.cls = 1;
+    p.Mc = p.N * (p.Ho / p.stride) * (p.Wo / p.stride);
+    p.tpc = cdiv(p.Mc, BM);
+    tiles_m = p.tpc * p.stride * p.stride;
+  }
+  int gy = 1;
+  if (p.ws != nullptr) {
+    const int nk = p.Kg / BK;
+    gy = p.ksplit;                 // requested number of slices
+    if (gy > nk) gy = nk;
+    p.ksplit = cdiv(nk, gy);       // K-stages per slice
+    gy = cdiv(nk, p.ksplit);
+  } else {
+    p.ksplit = 0;
+  }
   constexpr size_t smem = igemm_smem<MODE, BM, BN>();
   auto kern = igemm_kernel<MODE, BM, BN, WM, TR>;
   if (smem > 48 * 1024) {
@@ -294,7 +389,7 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
       return XR_E_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m * p.tiles_n, (unsigned)gy), dim3(NT), smem, st, p);
   XR_CHECK_LAUNCH("xr_conv_igemm");
   return XR_OK;
 }
@@ -528,13 +623,38 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __r
     const int tp = (int)(r % taps);
     const int64_t a = r / taps;
     const int64_t a1 = a / A2, a2 = a - a1 * A2;
-    const float v = packed[a * Kg + (int64_t)tp * Bp + b];
+    float* src = const_cast<float*>(packed) + a * Kg + (int64_t)tp * Bp + b;
+    const float v = *src;
+    if (accumulate & 2) *src = 0.f;  // read-and-clear: the slab is ready for the next step's atomics
     float* d = dst + a1 * sa1 + a2 * sa2 + tp * st_ + b * sb;
-    *d = accumulate ? (*d + v) : v;
+    *d = (accumulate & 1) ? (*d + v) : v;
+  }
+}
+
+template <typename T>
+__global__ void bias_cast_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ out, int64_t M,
+                                 int K, int ld) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < M * ld; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    float v = ws[i];
+    if (bias != nullptr && c < K) v += bias[c];
+    XrT<T>::st(out + i, c < ((K + 7) & ~7) ? v : XrT<T>::ld(out + i));
   }
 }
 
 }  // namespace
+
+extern "C" int xr_bias_cast(int dtype, const float* ws, const float* bias, void* out, int64_t M, int K, int ld, void* stream) {
+  XR_CHECK_ARG((dtype == XR_BF16 || dtype == XR_F32) && ws && out && M > 0 && K > 0 && ld >= K, "xr_bias_cast: bad arguments");
+  int blocks = (int)((M * ld + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == XR_BF16)
+    hipLaunchKernelGGL(bias_cast_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, bias, (bf16_t*)out, M, K, ld);
+  else
+    hipLaunchKernelGGL(bias_cast_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ws, bias, (float*)out, M, K, ld);
+  XR_CHECK_LAUNCH("xr_bias_cast");
+  return XR_OK;
+}
 
 extern "C" int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int taps, int B, int Bp,
                               int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, void* stream) {
@@ -564,9 +684,10 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
 
 extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
-                             int transposed, int Kg, int ldo, void* stream) {
+                             int transposed, int Kg, int ldo, float* splitk_ws, int splitk, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
-  XR_CHECK_ARG(in && w && out, "xr_conv_igemm: null pointer");
+  XR_CHECK_ARG((splitk_ws == nullptr) == (splitk <= 1), "xr_conv_igemm: split-K needs both a workspace and splitk > 1");
+  XR_CHECK_ARG(in && w && (out || splitk_ws), "xr_conv_igemm: null pointer");
   XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "xr_conv_igemm: non-positive dimension");
   XR_CHECK_ARG(C % 8 == 0, "xr_conv_igemm: C=%d must be a multiple of 8 (pad channels)", C);
@@ -583,7 +704,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0};
   hipStream_t st = (hipStream_t)stream;
   const bool wide = K > 64;
   if (dtype == XR_BF16) {

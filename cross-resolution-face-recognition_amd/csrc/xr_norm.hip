@@ -364,16 +364,19 @@ __global__ __launch_bounds__(NT) void se_excite_bwd_kernel(const float* __restri
   }
 }
 
-// out[i][j] (+)= scale * sum_n A[n][i] * B[n][j]   (tiny outer-product accumulation; I*J threads)
+// out[i][j] += scale * sum_n A[n][i] * B[n][j]   (tiny outer-product accumulation): blockIdx.y slices the n range,
+// 8 independent partial sums per thread keep loads in flight, one atomic per (output, slice)
 __global__ void small_atb_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out, int N,
-                                 int I, int J, float scale, int accumulate) {
+                                 int I, int J, float scale, int nper) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= I * J) return;
   const int i = idx / J, j = idx - i * J;
+  const int n0 = blockIdx.y * nper;
+  const int n1 = n0 + nper < N ? n0 + nper : N;
   float a = 0.f;
-  for (int n = 0; n < N; ++n) a += A[(size_t)n * I + i] * B[(size_t)n * J + j];
-  a *= scale;
-  out[idx] = accumulate ? out[idx] + a : a;
+#pragma unroll 8
+  for (int n = n0; n < n1; ++n) a += A[(size_t)n * I + i] * B[(size_t)n * J + j];
+  atomicAdd(out + idx, a * scale);
 }
 
 template <typename T>
@@ -504,8 +507,17 @@ extern "C" int xr_se_excite_bwd(const float* w1, const float* w2, const float* h
 extern "C" int xr_small_atb(const float* A, const float* B, float* out, int N, int I, int J, float scale, int accumulate,
                             void* stream) {
   XR_CHECK_ARG(A && B && out && N > 0 && I > 0 && J > 0, "xr_small_atb: bad arguments");
-  hipLaunchKernelGGL(small_atb_kernel, dim3(cdiv((long long)I * J, 256)), dim3(256), 0, (hipStream_t)stream, A, B, out, N, I, J,
-                     scale, accumulate);
+  if (!accumulate) {
+    if (hipMemsetAsync(out, 0, (size_t)I * J * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      xr_set_error("xr_small_atb: memset failed");
+      return XR_E_LAUNCH;
+    }
+  }
+  int slices = N >= 64 ? 16 : 1;
+  const int nper = cdiv(N, slices);
+  slices = cdiv(N, nper);
+  hipLaunchKernelGGL(small_atb_kernel, dim3(cdiv((long long)I * J, 256), slices), dim3(256), 0, (hipStream_t)stream, A, B, out,
+                     N, I, J, scale, nper);
   XR_CHECK_LAUNCH("xr_small_atb");
   return XR_OK;
 }

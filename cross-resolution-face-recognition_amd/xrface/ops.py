@@ -44,6 +44,86 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _ZeroPool:
+    """Small fp32 scratch buffers that must start at zero (statistic sums, reduction slabs, loss scalars) are carved
+    from one pre-zeroed slab: one memset per ~64 MB instead of one fill launch per buffer.  A carved view keeps its
+    slab alive; slabs are never reused after being dirtied."""
+
+    def __init__(self, nfloats=1 << 24):
+        self.cap = nfloats
+        self.buf = None
+        self.off = 0
+
+    def get(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 3) // 4 * 4
+        if n_al > self.cap // 4:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.cap:
+            self.buf = torch.zeros(self.cap, dtype=torch.float32, device=device)
+            self.off = 0
+        # .data: same storage (keeps the slab alive) but its own autograd version counter -- views of one slab would
+        # otherwise share a counter and trip save_for_backward's in-place-modification check
+        v = self.buf[self.off:self.off + n].view(shape).data
+        self.off += n_al
+        return v
+
+
+_zpool = _ZeroPool()
+
+
+def zeros_f32(shape, device):
+    return _zpool.get(tuple(shape) if not isinstance(shape, int) else (shape,), device)
+
+
+def _direct(p):
+    """Parameters re-pointed into a flat gradient buffer (parallel.FlatParams) take their gradient by in-kernel
+    accumulation into ``p.grad`` -- no autograd AccumulateGrad add, no temporary.  Returns the target or None."""
+    if getattr(p, "_xr_direct", False) and p.grad is not None:
+        return p.grad
+    return None
+
+
+def _direct_done(p):
+    hook = getattr(p, "_xr_grad_hook", None)
+    if hook is not None:
+        hook(p)
+
+
+def _wslab(w, K, kg):
+    """Persistent, always-zero-between-steps fp32 slab [K][kg] for the weight-gradient atomics (the unpack kernel
+    reads AND clears it)."""
+    slab = w.__dict__.get("_xr_slab")
+    if slab is None or slab.shape != (K, kg) or slab.device != w.device:
+        slab = torch.zeros((K, kg), dtype=torch.float32, device=w.device)
+        w.__dict__["_xr_slab"] = slab
+    return slab
+
+
+def _emit_wgrad(w, slab, A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb):
+    """slab -> gradient in the parameter's own layout; direct accumulation into w.grad when enabled."""
+    tgt = _direct(w)
+    if tgt is not None:
+        lib.xr_unpack_wgrad(ptr(slab), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 3, stream())
+        _direct_done(w)
+        return None
+    dw = torch.empty_like(w, dtype=torch.float32)
+    lib.xr_unpack_wgrad(ptr(slab), ptr(dw), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 2, stream())
+    return dw
+
+
+def _emit_small(p, val):
+    """Small fp32 gradient vector (bias / gamma / beta / alpha): add into p.grad directly when enabled."""
+    tgt = _direct(p)
+    if tgt is not None and val is not None:
+        tgt.add_(val.view_as(tgt))
+        _direct_done(p)
+        return None
+    return val
+
+
 # ------------------------------------------------------------------------------------------------- weight packs
 _pack_epoch = [0]
 
@@ -158,9 +238,9 @@ def leave2d(buf):
 # ------------------------------------------------------------------------------------------------- convolution
 def _bias_grad(dy, K):
     N, Ho, Wo, Kp = dy.shape
-    sums = torch.zeros((2, 1, Kp), dtype=torch.float32, device=dy.device)
+    sums = zeros_f32((2, 1, Kp), dy.device)
     lib.xr_group_stats(dt(dy), ptr(dy), ptr(sums), 1, N * Ho * Wo, Kp, stream())
-    return sums[0, 0, :K].clone()
+    return sums[0, 0, :K]
 
 
 class _Conv2d(Function):
@@ -179,9 +259,10 @@ class _Conv2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, stream())
+                          kg, Kp, None, 0, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
+        ctx.bias_ref = b
         return y
 
     @staticmethod
@@ -199,16 +280,15 @@ class _Conv2d(Function):
             pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, stream())
+                              kg, Cp, None, 0, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
-            dwp = torch.zeros((K, kg), dtype=torch.float32, device=x.device)
+            dwp = _wslab(w, K, kg)
             lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg,
                               _wgrad_split(N * Ho * Wo, K, kg), stream())
-            dw = torch.empty_like(w, dtype=torch.float32)
-            lib.xr_unpack_wgrad(ptr(dwp), ptr(dw), K, 1, R * S, C, Cp, kg, C * R * S, 0, 1, R * S, 0, stream())
+            dw = _emit_wgrad(w, dwp, K, 1, R * S, C, Cp, kg, C * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
-            db = _bias_grad(dy, K)
+            db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db, None, None
 
 
@@ -229,9 +309,10 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
-                          kg, Kp, stream())
+                          kg, Kp, None, 0, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
+        ctx.bias_ref = b
         return y
 
     @staticmethod
@@ -250,17 +331,16 @@ class _ConvTranspose2d(Function):
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
-                              kg, Cp, stream())
+                              kg, Cp, None, 0, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
             kg = kg_of(R * S, Cp)
-            dwp = torch.zeros((Cout, kg), dtype=torch.float32, device=x.device)
+            dwp = _wslab(w, Cout, kg)
             lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1, Kp, kg,
                               _wgrad_split(N * Ho * Wo, Cout, kg), stream())
-            dw = torch.empty_like(w, dtype=torch.float32)
-            lib.xr_unpack_wgrad(ptr(dwp), ptr(dw), Cout, 1, R * S, Cin, Cp, kg, R * S, 0, 1, Cout * R * S, 0, stream())
+            dw = _emit_wgrad(w, dwp, Cout, 1, R * S, Cin, Cp, kg, R * S, 0, 1, Cout * R * S)
         if has_b and ctx.needs_input_grad[2]:
-            db = _bias_grad(dy, Cout)
+            db = _emit_small(ctx.bias_ref, _bias_grad(dy, Cout))
         return dx, dw, db, None, None, None
 
 
@@ -279,9 +359,19 @@ class _LinearNHWC(Function):
         Kp = r8(K)
         y = torch.empty((N, 1, 1, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, stream())
+        tiles = ((N + 127) // 128) * ((Kp + 127) // 128)
+        split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
+        if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
+            ws = zeros_f32((N, Kp), x.device)
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split,
+                              stream())
+            lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
+        else:
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0,
+                              stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
+        ctx.bias_ref = b
         return y
 
     @staticmethod
@@ -299,15 +389,14 @@ class _LinearNHWC(Function):
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
-                              HW * C, stream())
+                              HW * C, None, 0, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
-            dwp = torch.zeros((K, kg), dtype=torch.float32, device=x.device)
+            dwp = _wslab(w, K, kg)
             lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, stream())
-            dw = torch.empty_like(w, dtype=torch.float32)
-            lib.xr_unpack_wgrad(ptr(dwp), ptr(dw), K, 1, HW, C, C, kg, C * HW, 0, 1, HW, 0, stream())
+            dw = _emit_wgrad(w, dwp, K, 1, HW, C, C, kg, C * HW, 0, 1, HW)
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = _bias_grad(dy, K)
+            db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db
 
 
@@ -347,7 +436,7 @@ class _NormAct(Function):
         al = None if alpha is None else _c(alpha.detach().float())
         mean = invstd = scale = shift = None
         if stats:
-            sums = torch.zeros((2, G, C), **f32)
+            sums = zeros_f32((2, G, C), dev)
             lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
             mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
@@ -362,6 +451,7 @@ class _NormAct(Function):
         lib.xr_affine_act(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), G, rows, C, 1, stream())
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, gm, al, rmean, rvar)
         ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
+        ctx.prefs = (gamma, beta, alpha)
         return y
 
     @staticmethod
@@ -372,27 +462,44 @@ class _NormAct(Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         f32 = dict(dtype=torch.float32, device=x.device)
-        red = torch.zeros((3, G, C), **f32)
+        red = zeros_f32((3, G, C), x.device)
         lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red), G, rows, C,
                                      1, stream())
         dgamma = dbeta = dalpha = None
         coef = None
+        p_g, p_b, p_a = ctx.prefs
         if stats:
             coef = torch.empty((3, G, C), **f32)
-            dgamma = torch.zeros(C, **f32) if has_g else None
-            dbeta = torch.zeros(C, **f32) if has_b else None
-            dalpha = torch.zeros(C, **f32) if has_a else None
+            # xr_norm_bwd_coeffs ACCUMULATES into its dgamma/dbeta/dalpha pointers: aim it at .grad when direct
+            t_g, t_b, t_a = (_direct(p_g) if has_g else None), (_direct(p_b) if has_b else None), (_direct(p_a) if has_a else None)
+            dgamma = (t_g if t_g is not None else zeros_f32((C,), x.device)) if has_g else None
+            dbeta = (t_b if t_b is not None else zeros_f32((C,), x.device)) if has_b else None
+            dalpha = (t_a if t_a is not None else zeros_f32((C,), x.device)) if has_a else None
             lib.xr_norm_bwd_coeffs(ptr(red), ptr(gm), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dalpha),
                                    G, rows, C, stream())
+            if t_g is not None:
+                dgamma = None
+                _direct_done(p_g)
+            if t_b is not None:
+                dbeta = None
+                _direct_done(p_b)
+            if t_a is not None:
+                dalpha = None
+                _direct_done(p_a)
         else:
             if has_a:
-                dalpha = torch.empty(C, **f32)
-                lib.xr_reduce_groups(ptr(red[2]), ptr(dalpha), G, C, 0, stream())
+                t_a = _direct(p_a)
+                if t_a is not None:
+                    lib.xr_reduce_groups(ptr(red[2]), ptr(t_a), G, C, 1, stream())
+                    _direct_done(p_a)
+                else:
+                    dalpha = torch.empty(C, **f32)
+                    lib.xr_reduce_groups(ptr(red[2]), ptr(dalpha), G, C, 0, stream())
             if mode == "bn":
                 if has_b:
-                    dbeta = red[0, 0].clone()
+                    dbeta = _emit_small(p_b, red[0, 0])
                 if has_g:
-                    dgamma = (red[1, 0] - rmean * red[0, 0]) * torch.rsqrt(rvar + eps)
+                    dgamma = _emit_small(p_g, (red[1, 0] - rmean * red[0, 0]) * torch.rsqrt(rvar + eps))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[5]) else None
         if dx is not None or dres is not None:
@@ -417,7 +524,7 @@ class _SEScaleAdd(Function):
         N, H, W, C = r.shape
         Cr = w1.shape[0]
         f32 = dict(dtype=torch.float32, device=r.device)
-        sums = torch.zeros((2, N, C), **f32)
+        sums = zeros_f32((2, N, C), r.device)
         lib.xr_group_stats(dt(r), ptr(r), ptr(sums), N, H * W, C, stream())
         w1f, w2f = _c(w1.detach().float()), _c(w2.detach().float())
         hidden, s = torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
@@ -429,6 +536,7 @@ class _SEScaleAdd(Function):
         ctx.save_for_backward(r, w1f, w2f, hidden, s, sums)
         ctx.inv_hw = inv_hw
         ctx.has_sc = shortcut is not None
+        ctx.wrefs = (w1, w2)
         return y
 
     @staticmethod
@@ -440,21 +548,29 @@ class _SEScaleAdd(Function):
         N, H, W, C = r.shape
         Cr = hidden.shape[1]
         f32 = dict(dtype=torch.float32, device=r.device)
-        red = torch.zeros((3, N, C), **f32)
+        red = zeros_f32((3, N, C), r.device)
         # act none, no shift/res: dz = dy, red[1] = sum dy * r = ds
         lib.xr_affine_act_bwd_reduce(dt(r), ptr(r), None, None, None, None, ACT_NONE, ptr(dy), ptr(red), N, H * W, C, 1, stream())
         dpre2, dhid = torch.empty((N, C), **f32), torch.empty((N, Cr), **f32)
-        coef = torch.zeros((3, N, C), **f32)
+        coef = zeros_f32((3, N, C), r.device)
         coef[0].copy_(s)
         lib.xr_se_excite_bwd(ptr(w1f), ptr(w2f), ptr(hidden), ptr(s), ptr(red[1]), ptr(dpre2), ptr(dhid), ptr(coef[2]), N, C, Cr,
                              ctx.inv_hw, stream())
         dr = torch.empty_like(r)
         lib.xr_affine_act_bwd_apply(dt(r), ptr(r), None, None, None, None, ACT_NONE, ptr(dy), ptr(coef), ptr(dr), None, N, H * W, C,
                                     1, stream())
-        dw1 = torch.empty((Cr, C, 1, 1), **f32)
-        dw2 = torch.empty((C, Cr, 1, 1), **f32)
-        lib.xr_small_atb(ptr(dhid), ptr(sums[0]), ptr(dw1), N, Cr, C, ctx.inv_hw, 0, stream())
-        lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 0, stream())
+        w1, w2 = ctx.wrefs
+        t1, t2 = _direct(w1), _direct(w2)
+        dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), r.device)
+        dw2 = t2 if t2 is not None else zeros_f32((C, Cr, 1, 1), r.device)
+        lib.xr_small_atb(ptr(dhid), ptr(sums[0]), ptr(dw1), N, Cr, C, ctx.inv_hw, 1, stream())
+        lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 1, stream())
+        if t1 is not None:
+            dw1 = None
+            _direct_done(w1)
+        if t2 is not None:
+            dw2 = None
+            _direct_done(w2)
         return dr, dw1, dw2, (dy if ctx.has_sc else None)
 
 
@@ -646,7 +762,7 @@ class _MSE(Function):
         _need_cuda(a)
         assert a.shape == b.shape, f"mse: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
         a2, b2 = _same_layout(a.detach(), b.detach())
-        loss = torch.zeros((), dtype=torch.float32, device=a.device)
+        loss = zeros_f32((1,), a.device).view(())
         n = a2.numel()
         lib.xr_loss_mse(dt(a2), ptr(a2), ptr(b2), scale, 1.0, ptr(loss), None, None, n, n, None, stream())
         ctx.save_for_backward(a2, b2)
@@ -679,7 +795,7 @@ class _Landmark(Function):
         t = _c(target.detach().float())
         N, C, H, W = p.shape
         assert t.numel() == N * H * W
-        loss = torch.zeros((), dtype=torch.float32, device=p.device)
+        loss = zeros_f32((1,), p.device).view(())
         lib.xr_loss_landmark(ptr(p), ptr(t), scale, 1.0, ptr(loss), None, N, C, H * W, None, stream())
         ctx.save_for_backward(p, t)
         ctx.meta = (scale, pred.dtype)
@@ -705,7 +821,7 @@ class _CE2d(Function):
         p = _c(pred.detach().float())
         N, C, H, W = p.shape
         t = _c(target.detach().reshape(N, H * W).long())
-        loss = torch.zeros((), dtype=torch.float32, device=p.device)
+        loss = zeros_f32((1,), p.device).view(())
         lib.xr_loss_ce_nchw(ptr(p), ptr(t), 1.0, ptr(loss), None, N, C, H * W, None, stream())
         ctx.save_for_backward(p, t)
         ctx.pdt = pred.dtype
@@ -733,7 +849,7 @@ class _CERows(Function):
         x = _c(x)
         M, C = x.shape
         t = _c(target.detach().long())
-        loss = torch.zeros((), dtype=torch.float32, device=x.device)
+        loss = zeros_f32((1,), x.device).view(())
         lib.xr_loss_softmax_ce(dt(x), ptr(x), ptr(t), 1.0, ptr(loss), None, M, C, C, None, stream())
         ctx.save_for_backward(x, t)
         ctx.ldt = logits.dtype

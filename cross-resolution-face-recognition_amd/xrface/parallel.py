@@ -18,7 +18,7 @@ from ._lib import lib, ptr, stream
 class FlatParams:
     """Re-point ``p.data`` / ``p.grad`` of every trainable parameter into two flat fp32 buffers."""
 
-    def __init__(self, params, align=64):
+    def __init__(self, params, align=64, direct=True):
         self.params = [p for p in params if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev = self.params[0].device
@@ -35,6 +35,7 @@ class FlatParams:
             v.copy_(p.data)
             p.data = v
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._xr_direct = direct  # HIP backward kernels accumulate straight into p.grad (see ops._direct)
 
     def zero_grad(self):
         """One memset; .grad tensors stay allocated views (autograd accumulates in place)."""
@@ -46,9 +47,13 @@ class FlatParams:
 
 class BucketedAllReduce:
     """Average ``flat.grad`` across ranks in ~bucket_mb slices, each launched as soon as the last of its
-    parameters has accumulated its gradient (reverse registration order ~ reverse execution order)."""
+    parameters has accumulated its gradient (reverse registration order ~ reverse execution order).
 
-    def __init__(self, flat: FlatParams, bucket_mb: float = 48.0, group=None):
+    ``overlap=False`` defers every launch to ``finish()``: required when FlatParams(direct=True) is combined with a
+    model that applies one parameter at several sites (the shared FSRNet trunks), because the direct-accumulation
+    path signals per site, not per parameter."""
+
+    def __init__(self, flat: FlatParams, bucket_mb: float = 48.0, group=None, overlap: bool = True):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -73,9 +78,11 @@ class BucketedAllReduce:
         self._works = []
         self._hooks = []
         self.enabled = self.world > 1
-        if self.enabled:
+        if self.enabled and overlap:
             for i, p in enumerate(flat.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                h = self._make_hook(i)
+                self._hooks.append(p.register_post_accumulate_grad_hook(h))
+                p._xr_grad_hook = h  # direct-accumulation path bypasses AccumulateGrad: it calls the hook itself
         self.reset()
 
     def reset(self):
@@ -95,7 +102,7 @@ class BucketedAllReduce:
         def hook(_p):
             b = self.bucket_of[i]
             self._pending[b] -= 1
-            if self._pending[b] == 0:
+            if self._pending[b] == 0:  # a parameter used at several sites may fire more than once: launch only once
                 self._launch(b)
         return hook
 

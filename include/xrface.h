@@ -70,7 +70,13 @@ int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int
  * offset 0 of the caller's pointer (lets producers write into a concat buffer). */
 int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                   int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
-                  int transposed, int Kg, int ldo, void* stream);
+                  int transposed, int Kg, int ldo, float* splitk_ws, int splitk, void* stream);
+/* split-K (long reductions with few output tiles, e.g. Linear(25088->512) at batch 256): splitk > 1 slices of the
+ * K loop accumulate with fp32 atomics into splitk_ws [N*Ho*Wo][ldo] (zeroed by the caller); `out` is then
+ * produced by xr_bias_cast.  splitk_ws == NULL / splitk <= 1: direct epilogue.
+ * Transposed gathers with stride > 1 run class-wise: output pixels are grouped by (ho % stride, wo % stride)
+ * and each group only visits the taps it can see (no multiply-by-zero work). */
+int xr_bias_cast(int dtype, const float* ws, const float* bias, void* out, int64_t M, int K, int ld, void* stream);
 
 /* Weight gradient (aten::convolution_backward weight part; same call sites as above).
  * dwp[k][t*C + c] += sum_m dy[m][k] * gather(in)[m][t][c]      (fp32, PACKED layout [K][Kg], atomics;
@@ -80,7 +86,9 @@ int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, v
 int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,
                   int Wo, int K, int R, int S, int stride, int pad, int transposed, int ldy, int Kg, int split,
                   void* stream);
-/* Inverse of xr_pack_weight for gradients: dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= packed[a][t*Bp + b]. */
+/* Inverse of xr_pack_weight for gradients: dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= packed[a][t*Bp + b].
+ * accumulate bit 0: add into dst instead of overwriting; bit 1: zero the packed slab after reading
+ * (read-and-clear, so a persistent slab needs no memset before the next step's atomics). */
 int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,
                     int64_t sa1, int64_t sa2, int64_t st, int64_t sb, int accumulate, void* stream);
 
