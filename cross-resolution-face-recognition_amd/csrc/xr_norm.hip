@@ -53,11 +53,49 @@ __device__ __forceinline__ void load_coef8(const float* p, int idx, float (&v)[8
   }
 }
 
-// block-level reduction of NV per-thread 8-vectors over the rpb row-lanes, then atomics to dst[v][g][c]
+// block-level reduction of NV per-thread 8-vectors over the rpb row-lanes, then ONE atomic per (vector, channel).
+// Threads sharing a channel chunk sit cpr lanes apart: when cpr is a power of two <= 64 the in-wave part is a
+// shuffle-xor ladder (no LDS, no barrier); the four per-wave results meet in LDS once.
 template <int NV>
-__device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV][8], float* dst, int G, int g, int C, int cch, int rsub,
-                                                    int rpb, bool active, float* lds) {
-  // lds: [rpb][C] floats per vector, processed one vector at a time
+__device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV][8], float* dst, int G, int g, int C, int cpr, int cch,
+                                                    int rsub, int rpb, bool active, float* lds) {
+  const int t = threadIdx.x;
+  const bool pow2 = (cpr & (cpr - 1)) == 0 && cpr <= 64;
+  if (pow2) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = acc[v][e];
+        for (int o = cpr; o < 64; o <<= 1) x += __shfl_xor(x, o, 64);
+        acc[v][e] = x;
+      }
+    // lanes 0..cpr-1 of each wave now hold the wave's sums for chunk (lane % cpr); waves cover different rows
+    const int lane = t & 63, wave = t >> 6;
+    const int nw = NT / 64;
+    if (cpr == 64) {
+      // every wave owns whole rows: combine the 4 waves through LDS [nw][NV][C]
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[(wave * NV + v) * C + lane * 8 + e] = acc[v][e];
+    } else if (lane < cpr) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lds[(wave * NV + v) * C + lane * 8 + e] = acc[v][e];
+    }
+    __syncthreads();
+    for (int i = t; i < NV * C; i += NT) {
+      const int v = i / C, c = i - v * C;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < nw; ++w) s += lds[(w * NV + v) * C + c];
+      atomicAdd(dst + ((size_t)v * G + g) * C + c, s);
+    }
+    return;
+  }
+  // generic path: lds [rpb][C] floats, one vector at a time
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     __syncthreads();
@@ -66,7 +104,7 @@ __device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV][8], float* 
       for (int e = 0; e < 8; ++e) lds[rsub * C + cch * 8 + e] = acc[v][e];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += NT) {
+    for (int c = t; c < C; c += NT) {
       float s = 0.f;
       for (int r = 0; r < rpb; ++r) s += lds[r * C + c];
       atomicAdd(dst + ((size_t)v * G + g) * C + c, s);
@@ -89,7 +127,20 @@ __global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x
   for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = 0.f;
   if (active) {
     const T* base = x + ((size_t)g * geo.rows) * geo.C + cch * 8;
-    for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+    int r = r_begin + rsub;
+    for (; r + 3 * geo.rpb < r_end; r += 4 * geo.rpb) {  // 4 independent 16-B loads in flight per lane
+      float v0[8], v1[8], v2[8], v3[8];
+      ld8(base + (size_t)r * geo.C, v0);
+      ld8(base + (size_t)(r + geo.rpb) * geo.C, v1);
+      ld8(base + (size_t)(r + 2 * geo.rpb) * geo.C, v2);
+      ld8(base + (size_t)(r + 3 * geo.rpb) * geo.C, v3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        acc[0][e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
+        acc[1][e] += (v0[e] * v0[e] + v1[e] * v1[e]) + (v2[e] * v2[e] + v3[e] * v3[e]);
+      }
+    }
+    for (; r < r_end; r += geo.rpb) {
       float v[8];
       ld8(base + (size_t)r * geo.C, v);
 #pragma unroll
@@ -99,7 +150,7 @@ __global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x
       }
     }
   }
-  block_reduce_atomic<2>(acc, sums, geo.G, g, geo.C, cch, rsub, geo.rpb, active, lds);
+  block_reduce_atomic<2>(acc, sums, geo.G, g, geo.C, geo.cpr, cch, rsub, geo.rpb, active, lds);
 }
 
 __global__ void norm_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
@@ -213,7 +264,7 @@ __global__ __launch_bounds__(NT) void affine_act_bwd_reduce_kernel(AffP p, Geo g
       }
     }
   }
-  block_reduce_atomic<3>(acc, p.red, geo.G, g, geo.C, cch, rsub, geo.rpb, active, lds);
+  block_reduce_atomic<3>(acc, p.red, geo.G, g, geo.C, geo.cpr, cch, rsub, geo.rpb, active, lds);
 }
 
 __global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
@@ -247,12 +298,24 @@ __global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const floa
 }
 
 // sums red[v][g][c] over g into out[c] (used for PReLU-only dalpha and bias gradients)
+// blockIdx.y = vector v: out[v][c] (+)= sum_g red[v][g][c]; 256 threads = (C-chunk of 32) x 8 group-lanes
 __global__ void reduce_groups_kernel(const float* __restrict__ red, float* __restrict__ out, int G, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float part[8][32];
+  const int cl = threadIdx.x & 31, gl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const float* base = red + (size_t)blockIdx.y * G * C;
   float s = 0.f;
-  for (int g = 0; g < G; ++g) s += red[(size_t)g * C + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < C)
+    for (int g = gl; g < G; g += 8) s += base[(size_t)g * C + c];
+  part[gl][cl] = s;
+  __syncthreads();
+  if (gl == 0 && c < C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += part[k][cl];
+    float* o = out + (size_t)blockIdx.y * C + c;
+    *o = accumulate ? *o + tot : tot;
+  }
 }
 
 template <typename T>
@@ -399,7 +462,7 @@ extern "C" int xr_group_stats(int dtype, const void* x, float* sums, int G, int 
   if (int e = check_geo("xr_group_stats", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && sums, "xr_group_stats: null pointer");
   Geo geo = make_geo(G, rows, C, 2048);
-  const size_t smem = (size_t)geo.rpb * C * sizeof(float);
+  const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
   if (dtype == XR_BF16)
     hipLaunchKernelGGL(group_stats_kernel<bf16_t>, geo_grid(geo), dim3(NT), smem, (hipStream_t)stream, (const bf16_t*)x, sums, geo);
   else
@@ -450,7 +513,7 @@ extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* s
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_reduce: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, nullptr, dy, red, nullptr, nullptr, nullptr, coef_per_group};
   Geo geo = make_geo(G, rows, C, 2048);
-  const size_t smem = (size_t)geo.rpb * C * sizeof(float);
+  const size_t smem = (size_t)(geo.rpb > 12 ? geo.rpb : 12) * C * sizeof(float);
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_bwd_reduce_kernel<bf16_t>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_reduce");
   return launch_aff<float>(affine_act_bwd_reduce_kernel<float>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_reduce");
@@ -465,9 +528,9 @@ extern "C" int xr_norm_bwd_coeffs(const float* red, const float* gamma, const fl
   return XR_OK;
 }
 
-extern "C" int xr_reduce_groups(const float* red, float* out, int G, int C, int accumulate, void* stream) {
-  XR_CHECK_ARG(red && out && G > 0 && C > 0, "xr_reduce_groups: bad arguments");
-  hipLaunchKernelGGL(reduce_groups_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, out, G, C, accumulate);
+extern "C" int xr_reduce_groups(const float* red, float* out, int NV, int G, int C, int accumulate, void* stream) {
+  XR_CHECK_ARG(red && out && NV > 0 && G > 0 && C > 0, "xr_reduce_groups: bad arguments");
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3(cdiv(C, 32), NV), dim3(256), 0, (hipStream_t)stream, red, out, G, C, accumulate);
   XR_CHECK_LAUNCH("xr_reduce_groups");
   return XR_OK;
 }

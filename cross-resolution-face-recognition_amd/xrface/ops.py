@@ -435,9 +435,17 @@ class _NormAct(Function):
         bt = None if beta is None else _c(beta.detach().float())
         al = None if alpha is None else _c(alpha.detach().float())
         mean = invstd = scale = shift = None
+        # BatchNorm sums are taken per image (few blocks per atomic address) and folded over the batch afterwards
+        per_img = mode != "in" and N > 1 and H * W >= 16
         if stats:
-            sums = zeros_f32((2, G, C), dev)
-            lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
+            if per_img:
+                sums_n = zeros_f32((2, N, C), dev)
+                lib.xr_group_stats(dt(x), ptr(x), ptr(sums_n), N, H * W, C, stream())
+                sums = torch.empty((2, 1, C), **f32)
+                lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, N, C, 0, stream())
+            else:
+                sums = zeros_f32((2, G, C), dev)
+                lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
             mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             upd = mode == "bn" and rmean is not None
@@ -452,6 +460,7 @@ class _NormAct(Function):
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, gm, al, rmean, rvar)
         ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
         ctx.prefs = (gamma, beta, alpha)
+        ctx.per_img = (per_img, N, H * W)
         return y
 
     @staticmethod
@@ -462,9 +471,17 @@ class _NormAct(Function):
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
         f32 = dict(dtype=torch.float32, device=x.device)
-        red = zeros_f32((3, G, C), x.device)
-        lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red), G, rows, C,
-                                     1, stream())
+        per_img, N_, HW_ = ctx.per_img
+        if per_img:
+            red_n = zeros_f32((3, N_, C), x.device)
+            lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red_n), N_, HW_,
+                                         C, 0, stream())
+            red = torch.empty((3, 1, C), **f32)
+            lib.xr_reduce_groups(ptr(red_n), ptr(red), 3, N_, C, 0, stream())
+        else:
+            red = zeros_f32((3, G, C), x.device)
+            lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red), G, rows,
+                                         C, 1, stream())
         dgamma = dbeta = dalpha = None
         coef = None
         p_g, p_b, p_a = ctx.prefs
@@ -490,11 +507,11 @@ class _NormAct(Function):
             if has_a:
                 t_a = _direct(p_a)
                 if t_a is not None:
-                    lib.xr_reduce_groups(ptr(red[2]), ptr(t_a), G, C, 1, stream())
+                    lib.xr_reduce_groups(ptr(red[2]), ptr(t_a), 1, G, C, 1, stream())
                     _direct_done(p_a)
                 else:
                     dalpha = torch.empty(C, **f32)
-                    lib.xr_reduce_groups(ptr(red[2]), ptr(dalpha), G, C, 0, stream())
+                    lib.xr_reduce_groups(ptr(red[2]), ptr(dalpha), 1, G, C, 0, stream())
             if mode == "bn":
                 if has_b:
                     dbeta = _emit_small(p_b, red[0, 0])

@@ -138,8 +138,9 @@ int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, 
 int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                             const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
                             int G, int rows, int C, int coef_per_group, void* stream);
-/* out[c] (+)= sum_g red[g][c]  (PReLU-only dalpha, conv-bias gradients from xr_group_stats sums) */
-int xr_reduce_groups(const float* red, float* out, int G, int C, int accumulate, void* stream);
+/* out[v][c] (+)= sum_g red[v][g][c], v < NV.  BatchNorm statistics / backward sums are taken per image
+ * (G = N: at most a few blocks contend on one atomic address) and folded over the batch here. */
+int xr_reduce_groups(const float* red, float* out, int NV, int G, int C, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SE excitation (model_irse.py:40-46): s[n][c] = sigmoid(W2 relu(W1 (pooled_sum[n]/HW))), Cr = C/16.
