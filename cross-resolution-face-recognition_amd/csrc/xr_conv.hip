@@ -20,6 +20,28 @@ namespace {
 constexpr int BK = 64;        // reduction elements per LDS stage
 constexpr int NT = 256;       // threads per workgroup (4 waves)
 
+// division by a launch-invariant 32-bit divisor: q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(magic, n)
+// (Granlund-Montgomery round-up form, exact for every 32-bit n); d == 1 is special-cased.
+struct FastDiv {
+  unsigned magic, shift, d;
+};
+static FastDiv make_fd(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.shift = l;
+  return f;
+}
+__device__ __forceinline__ int fdiv(const FastDiv& f, int n) {
+  if (f.d <= 1) return n;
+  const unsigned un = (unsigned)n;
+  const unsigned t = __umulhi(f.magic, un);
+  return (int)((t + ((un - t) >> 1)) >> (f.shift - 1));
+}
+
 struct IgemmP {
   const void* in;
   const bf16_t* w;  // NS planes of [K][Kg] bf16, plane stride K*Kg
@@ -29,18 +51,20 @@ struct IgemmP {
   int cls, tpc, Mc;   // class mode (transposed gather, stride > 1): output pixels grouped by (ho % s, wo % s)
   float* ws;          // split-K fp32 workspace [M][ldo] (atomics) or nullptr
   int ksplit;         // K-stages per blockIdx.y slice (split-K), 0 = no split
+  FastDiv fd_howo, fd_wo, fd_c, fd_s, fd_hqwq, fd_wq, fd_tn, fd_st;
+  unsigned in_bytes, w_bytes;  // buffer-descriptor extents (FAST path)
 };
 
 // decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
 template <bool TR>
-__device__ __forceinline__ void decode_pixel(int m, int M, int HoWo, int Wo, int HW, int stride, int pad, bool& valid,
-                                             int& nb, int& oh0, int& ow0) {
+__device__ __forceinline__ void decode_pixel(int m, int M, const FastDiv& fd_howo, const FastDiv& fd_wo, int HW, int stride,
+                                             int pad, bool& valid, int& nb, int& oh0, int& ow0) {
   valid = m < M;
   int mm = valid ? m : 0;
-  int n = mm / HoWo;
-  int rem = mm - n * HoWo;
-  int ho = rem / Wo;
-  int wo = rem - ho * Wo;
+  int n = fdiv(fd_howo, mm);
+  int rem = mm - n * (int)fd_howo.d;
+  int ho = fdiv(fd_wo, rem);
+  int wo = rem - ho * (int)fd_wo.d;
   nb = n * HW;
   if (TR) {
     oh0 = ho + pad;
@@ -105,8 +129,16 @@ __device__ __forceinline__ f32x16_t mfma_split(const bf16x8_t (&a)[NS], const bf
 }
 
 // ------------------------------------------------------------------------------------------------ forward/dgrad
-template <int MODE, int BM, int BN, int WM, bool TR>
-__global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+#define XR_OOR 0x80000000u  // buffer offset beyond every descriptor extent used here: the load returns zeros
+
+// FAST: taps address the input linearly (forward conv of any stride, stride-1 dgrad, class-wise strided dgrad) and
+// C % 64 == 0, so a K-stage is one (tap, 64-channel chunk): per-row byte offsets and per-row tap-validity bitmasks are
+// computed once per tile, the per-stage part is scalar, and out-of-image taps are fetched as zeros by the buffer
+// range check -- ~4 VALU per gathered row per stage instead of ~15.
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
+__global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(IgemmP p) {
+  constexpr int NBUF = 1;
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int NS = MODE ? 3 : 1;
@@ -115,9 +147,8 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   using out_t = in_t;
   constexpr int PADE = 16 / sizeof(out_t);
 
+  constexpr int STAGE = NS * (BM + BN) * 128;        // NBUF == 2 double-buffers the LDS stage (one barrier per stage)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;
-  unsigned char* sB = smem + NS * BM * 128;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -128,10 +159,10 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tile_n = bid % p.tiles_n;
-  const int tile_m = bid / p.tiles_n;
+  const int tile_m = fdiv(p.fd_tn, bid);
+  const int tile_n = bid - tile_m * p.tiles_n;
   const int n0 = tile_n * BN;
-  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+  const int HW = p.H * p.W;
   const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
   // class mode bookkeeping (wave-uniform)
   const bool cls_mode = TR && p.cls;
@@ -148,16 +179,15 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   auto decode_row = [&](int row, bool& valid, int& nb, int& oh0, int& ow0) -> int {
     if (!cls_mode) {
       const int m = tile_m * BM + row;
-      decode_pixel<TR>(m, p.M, HoWo, p.Wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
+      decode_pixel<TR>(m, p.M, p.fd_howo, p.fd_wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
       return valid ? m : -1;
     }
     const int idx = t_in * BM + row;
     valid = idx < p.Mc;
-    const int Hq = p.Ho / p.stride, Wq = p.Wo / p.stride;
     const int ii = valid ? idx : 0;
-    const int n = ii / (Hq * Wq);
-    const int rem = ii - n * (Hq * Wq);
-    const int hq = rem / Wq, wq = rem - hq * Wq;
+    const int n = fdiv(p.fd_hqwq, ii);
+    const int rem = ii - n * (int)p.fd_hqwq.d;
+    const int hq = fdiv(p.fd_wq, rem), wq = rem - hq * (int)p.fd_wq.d;
     const int ho = hq * p.stride + ph, wo = wq * p.stride + pw;
     nb = n * HW; oh0 = ho + p.pad; ow0 = wo + p.pad;
     return valid ? (n * p.Ho + ho) * p.Wo + wo : -1;
@@ -175,12 +205,91 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
   uint4 b_u[NS][RB];
   const int taps = p.R * p.S;
 
+  // ---- FAST path state
+  constexpr int ESZ = (int)sizeof(in_t);
+  int a_off[FAST ? RA : 1];
+  unsigned a_mlo[FAST ? RA : 1];
+  unsigned b_off[FAST ? RB : 1];
+  __amdgpu_buffer_rsrc_t rsA, rsB;
+  int st_ti = 0, st_rr = 0, st_ss = 0, st_c0 = 0;   // wave-uniform stage cursor: tap index, tap row/col, channel chunk
+  const int nsw = cls_mode ? ns : p.S;
+  if constexpr (FAST) {
+    const int nrw = cls_mode ? nr : p.R;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      int ah = a_oh[i], aw = a_ow[i];
+      if (cls_mode) {
+        ah = fdiv(p.fd_st, ah - r0);
+        aw = fdiv(p.fd_st, aw - s0);
+      }
+      a_off[i] = ((a_nb[i] + ah * p.W + aw) * p.C + cc * 8) * ESZ;
+      unsigned lo = 0;
+      int ti = 0;
+      for (int rr = 0; rr < nrw; ++rr)
+        for (int ss = 0; ss < nsw; ++ss, ++ti) {
+          const int y = TR ? ah - rr : ah + rr, x = TR ? aw - ss : aw + ss;
+          const bool ok = a_valid[i] && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+          if (ok) lo |= 1u << ti;
+        }
+      a_mlo[i] = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int row = n0 + rbase + 32 * i;
+      b_off[i] = row < p.K ? (unsigned)((row * p.Kg + cc * 8) * 2) : XR_OOR;
+    }
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.w), 0, p.w_bytes, 0x00020000);
+  }
+  auto load_stage_fast = [&]() {
+    int dpix = st_rr * p.W + st_ss;
+    if (TR) dpix = -dpix;
+    const int dby = (dpix * p.C + st_c0) * ESZ;
+    const int wk = cls_mode ? ((r0 + st_rr * p.stride) * p.S + (s0 + st_ss * p.stride)) * p.C + st_c0 : st_ti * p.C + st_c0;
+    const unsigned sh = (unsigned)st_ti;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const unsigned voff = ((a_mlo[i] >> sh) & 1u) ? (unsigned)(a_off[i] + dby) : XR_OOR;
+      if constexpr (MODE == 1) {
+        const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, 0, 0);
+        const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff + 16u, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a_f[i][e] = __uint_as_float(u0[e]);
+          a_f[i][4 + e] = __uint_as_float(u1[e]);
+        }
+      } else {
+        const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, 0, 0);
+        a_u[i] = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+    }
+    const int plane = p.K * p.Kg * 2;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i], wk * 2 + q * plane, 0);
+        b_u[q][i] = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+    // advance the cursor to the next stage
+    st_c0 += BK;
+    if (st_c0 >= p.C) {
+      st_c0 = 0;
+      ++st_ti;
+      if (++st_ss == nsw) { st_ss = 0; ++st_rr; }
+    }
+  };
+
   auto load_stage = [&](int kk) {
+    if constexpr (FAST) {
+      load_stage_fast();
+      return;
+    }
     int k0, c, r, s;
     bool tap_ok;
     if (cls_mode) {  // only the taps this output class can see; C % 64 == 0 so a stage never straddles taps
       const int cpt = p.C >> 6;
-      const int ti = kk / cpt;
+      const int ti = kk / cpt;   // wave-uniform scalar division, once per stage
       c = (kk - ti * cpt) * BK + cc * 8;
       const int ri = ti / ns, si = ti - ri * ns;
       r = r0 + ri * p.stride; s = s0 + si * p.stride;
@@ -188,9 +297,9 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
       tap_ok = true;
     } else {
       k0 = kk * BK + cc * 8;
-      const int tap = k0 / p.C;
+      const int tap = fdiv(p.fd_c, k0);
       c = k0 - tap * p.C;
-      r = tap / p.S;
+      r = fdiv(p.fd_s, tap);
       s = tap - r * p.S;
       tap_ok = tap < taps;
     }
@@ -221,7 +330,9 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
     }
   };
 
-  auto store_stage = [&]() {
+  auto store_stage = [&](int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + NS * BM * 128;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int off = lds_off(rbase + 32 * i, cc);
@@ -258,12 +369,17 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
     kbeg = blockIdx.y * p.ksplit;
     nk = (kbeg + p.ksplit < nk) ? kbeg + p.ksplit : nk;
   }
+  if constexpr (FAST) {
+    const int cpt = p.C >> 6;
+    st_ti = kbeg / cpt;
+    st_c0 = (kbeg - st_ti * cpt) * BK;
+    st_rr = st_ti / nsw;
+    st_ss = st_ti - st_rr * nsw;
+  }
 
-  if (kbeg < nk) load_stage(kbeg);
-  for (int kk = kbeg; kk < nk; ++kk) {
-    store_stage();
-    __syncthreads();
-    if (kk + 1 < nk) load_stage(kk + 1);
+  auto compute_stage = [&](int buf) {
+    const unsigned char* sA = smem + buf * STAGE;
+    const unsigned char* sB = sA + NS * BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8_t fa[TM][NS], fb[TN][NS];
@@ -284,7 +400,32 @@ __global__ __launch_bounds__(NT) void igemm_kernel(IgemmP p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
     }
+  };
+
+  if constexpr (NBUF == 2) {
+    // stage kk lives in buffer kk&1: loads for kk+1 fly during the MFMAs of kk and are written to the OTHER
+    // buffer afterwards; a single barrier per stage orders both the RAW (next reads) and the WAR (next writes)
+    if (kbeg < nk) {
+      load_stage(kbeg);
+      store_stage(0);
+    }
     __syncthreads();
+    for (int kk = kbeg; kk < nk; ++kk) {
+      const int buf = (kk - kbeg) & 1;
+      if (kk + 1 < nk) load_stage(kk + 1);
+      compute_stage(buf);
+      if (kk + 1 < nk) store_stage(buf ^ 1);
+      __syncthreads();
+    }
+  } else {
+    if (kbeg < nk) load_stage(kbeg);
+    for (int kk = kbeg; kk < nk; ++kk) {
+      store_stage(0);
+      __syncthreads();
+      if (kk + 1 < nk) load_stage(kk + 1);
+      compute_stage(0);
+      __syncthreads();
+    }
   }
 
   if (p.ws != nullptr) {  // split-K: fp32 atomics into the workspace; bias/cast happen in xr_bias_cast
@@ -358,8 +499,28 @@ constexpr size_t igemm_smem() {
   return ops > stg ? ops : stg;
 }
 
+int g_tune[8] = {1, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm FAST gather path on/off, [1] wgrad LDS buffers (1|2)
+
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
+int launch_igemm_f(IgemmP& p, hipStream_t st);
+
 template <int MODE, int BM, int BN, int WM, bool TR>
 int launch_igemm(IgemmP& p, hipStream_t st) {
+  const bool cls_ok = TR && p.stride > 1 && p.Ho % p.stride == 0 && p.Wo % p.stride == 0 && p.C % 64 == 0 && p.ws == nullptr;
+  const long long in_bytes = (long long)p.N * p.H * p.W * p.C * (MODE ? 4 : 2);
+  const long long w_bytes = (long long)(MODE ? 3 : 1) * p.K * p.Kg * 2;
+  int ntaps = p.R * p.S;
+  if (cls_ok) ntaps = ((p.R + p.stride - 1) / p.stride) * ((p.S + p.stride - 1) / p.stride);
+  const bool fast = g_tune[0] && p.C % 64 == 0 && (!TR || p.stride == 1 || cls_ok) && ntaps <= 32 &&
+                    in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && p.Kg == p.R * p.S * p.C;
+  p.in_bytes = (unsigned)(in_bytes < (1ll << 31) ? in_bytes : 0x7FFFFFFF);
+  p.w_bytes = (unsigned)(w_bytes < (1ll << 31) ? w_bytes : 0x7FFFFFFF);
+  if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true>(p, st);
+  return launch_igemm_f<MODE, BM, BN, WM, TR, false>(p, st);
+}
+
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
+int launch_igemm_f(IgemmP& p, hipStream_t st) {
   p.tiles_n = cdiv((p.K + 7) / 8 * 8, BN);
   int tiles_m = cdiv(p.M, BM);
   p.cls = 0; p.tpc = 0; p.Mc = 0;
@@ -369,6 +530,14 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
     p.tpc = cdiv(p.Mc, BM);
     tiles_m = p.tpc * p.stride * p.stride;
   }
+  p.fd_howo = make_fd((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fd((unsigned)p.Wo);
+  p.fd_c = make_fd((unsigned)p.C);
+  p.fd_s = make_fd((unsigned)p.S);
+  p.fd_hqwq = make_fd((unsigned)((p.Ho / p.stride) * (p.Wo / p.stride) > 0 ? (p.Ho / p.stride) * (p.Wo / p.stride) : 1));
+  p.fd_wq = make_fd((unsigned)(p.Wo / p.stride > 0 ? p.Wo / p.stride : 1));
+  p.fd_tn = make_fd((unsigned)p.tiles_n);
+  p.fd_st = make_fd((unsigned)p.stride);
   int gy = 1;
   if (p.ws != nullptr) {
     const int nk = p.Kg / BK;
@@ -380,7 +549,7 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
     p.ksplit = 0;
   }
   constexpr size_t smem = igemm_smem<MODE, BM, BN>();
-  auto kern = igemm_kernel<MODE, BM, BN, WM, TR>;
+  auto kern = igemm_kernel<MODE, BM, BN, WM, TR, FAST>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
@@ -400,6 +569,7 @@ struct WgradP {
   const void* dy;
   float* dwp;
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c;
+  FastDiv fd_howo, fd_wo;
 };
 
 // transposing fragment fetch from a [pixel][col] LDS image (pitch bytes): 8 pixels x 1 column per lane
@@ -416,7 +586,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int pitch,
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int MODE, int BR, int BC, bool TR>
+template <int MODE, int BR, int BC, bool TR, int NBUF>
 __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int BP = 64;  // pixels per stage
   constexpr int NS = MODE ? 3 : 1;
@@ -427,14 +597,13 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int NY = BP * CRY / NT, NX = BP * CRX / NT;
   using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
 
+  constexpr int STAGE = NS * BP * (PY + PX);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sY = smem;
-  unsigned char* sX = smem + NS * BP * PY;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int tile_c = blockIdx.x % p.tiles_c, tile_r = blockIdx.x / p.tiles_c;
   const int r0 = tile_r * BR, c0 = tile_c * BC;
-  const int HoWo = p.Ho * p.Wo, HW = p.H * p.W;
+  const int HW = p.H * p.W;
   const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
   const in_t* __restrict__ dy = reinterpret_cast<const in_t*>(p.dy);
 
@@ -472,7 +641,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     for (int i = 0; i < NX; ++i) {
       const int m = mbase + xrow0 + (NT / CRX) * i;
       bool valid; int nb, oh0, ow0, pix = 0;
-      decode_pixel<TR>(m, p.M, HoWo, p.Wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
+      decode_pixel<TR>(m, p.M, p.fd_howo, p.fd_wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
       const bool ok = valid && col_ok && tap_coord<TR>(oh0, ow0, tr_, ts_, p.stride, p.H, p.W, pix);
       const in_t* src = in + ((size_t)(nb + pix) * p.C + cch);
       if constexpr (MODE == 1) {
@@ -486,7 +655,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       }
     }
   };
-  auto store_stage = [&]() {
+  auto store_stage = [&](int buf) {
+    unsigned char* sY = smem + buf * STAGE;
+    unsigned char* sX = sY + NS * BP * PY;
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
       const int off = (yrow0 + (NT / CRY) * i) * PY + ych * 16;
@@ -526,29 +697,48 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   int s_end = s_begin + p.steps_per_split;
   if (s_end > p.steps_total) s_end = p.steps_total;
 
+  auto compute_stage = [&](int buf) {
+    const unsigned char* sY = smem + buf * STAGE;
+    const unsigned char* sX = sY + NS * BP * PY;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8_t fa[2][NS], fb[2][NS];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fa[i][s] = tr_frag(sY + s * BP * PY, PY, ks * 16, wr0 + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fb[j][s] = tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
+    }
+  };
+
   if (s_begin < s_end) {
-    load_stage(s_begin);
-    for (int step = s_begin; step < s_end; ++step) {
-      store_stage();
+    if constexpr (NBUF == 2) {
+      load_stage(s_begin);
+      store_stage(0);
       __syncthreads();
-      if (step + 1 < s_end) load_stage(step + 1);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        bf16x8_t fa[2][NS], fb[2][NS];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int s = 0; s < NS; ++s) fa[i][s] = tr_frag(sY + s * BP * PY, PY, ks * 16, wr0 + i * 32, lane);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int s = 0; s < NS; ++s) fb[j][s] = tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
+      for (int step = s_begin; step < s_end; ++step) {
+        const int buf = (step - s_begin) & 1;
+        if (step + 1 < s_end) load_stage(step + 1);
+        compute_stage(buf);
+        if (step + 1 < s_end) store_stage(buf ^ 1);
+        __syncthreads();
       }
-      __syncthreads();
+    } else {
+      load_stage(s_begin);
+      for (int step = s_begin; step < s_end; ++step) {
+        store_stage(0);
+        __syncthreads();
+        if (step + 1 < s_end) load_stage(step + 1);
+        compute_stage(0);
+        __syncthreads();
+      }
     }
   }
 
@@ -567,10 +757,21 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     }
 }
 
+template <int MODE, int BR, int BC, bool TR, int NBUF>
+int launch_wgrad_nb(WgradP& p, int split, hipStream_t st);
+
 template <int MODE, int BR, int BC, bool TR>
 int launch_wgrad(WgradP& p, int split, hipStream_t st) {
+  if (MODE == 0 && g_tune[1] == 2) return launch_wgrad_nb<MODE, BR, BC, TR, MODE == 0 ? 2 : 1>(p, split, st);
+  return launch_wgrad_nb<MODE, BR, BC, TR, 1>(p, split, st);
+}
+
+template <int MODE, int BR, int BC, bool TR, int NBUF>
+int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
   constexpr int NS = MODE ? 3 : 1;
-  constexpr size_t smem = (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64));
+  constexpr size_t smem = (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64)) * NBUF;
+  p.fd_howo = make_fd((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fd((unsigned)p.Wo);
   p.tiles_c = cdiv(p.Kg, BC);
   const int tiles_r = cdiv(p.K, BR);
   p.steps_total = cdiv(p.M, 64);
@@ -578,7 +779,7 @@ int launch_wgrad(WgradP& p, int split, hipStream_t st) {
   if (split > p.steps_total) split = p.steps_total;
   p.steps_per_split = cdiv(p.steps_total, split);
   split = cdiv(p.steps_total, p.steps_per_split);
-  auto kern = wgrad_kernel<MODE, BR, BC, TR>;
+  auto kern = wgrad_kernel<MODE, BR, BC, TR, NBUF>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
@@ -644,6 +845,12 @@ __global__ void bias_cast_kernel(const float* __restrict__ ws, const float* __re
 
 }  // namespace
 
+extern "C" int xr_tune(int knob, int value) {
+  XR_CHECK_ARG(knob >= 0 && knob < 8, "xr_tune: knob out of range");
+  g_tune[knob] = value;
+  return XR_OK;
+}
+
 extern "C" int xr_bias_cast(int dtype, const float* ws, const float* bias, void* out, int64_t M, int K, int ld, void* stream) {
   XR_CHECK_ARG((dtype == XR_BF16 || dtype == XR_F32) && ws && out && M > 0 && K > 0 && ld >= K, "xr_bias_cast: bad arguments");
   int blocks = (int)((M * ld + 255) / 256);
@@ -704,7 +911,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool wide = K > 64;
   if (dtype == XR_BF16) {
@@ -726,7 +933,7 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
                ldy);
   XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_wgrad: bad Kg=%d", Kg);
   XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
-  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0};
+  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, {}, {}};
   hipStream_t st = (hipStream_t)stream;
   const bool tall = K > 64;
   if (dtype == XR_BF16) {

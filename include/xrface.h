@@ -46,6 +46,8 @@ const char* xr_last_error(void);
 int xr_version(void);
 /* number of CUs of the current device (used by hosts to size split factors); <0 on error */
 int xr_device_cus(void);
+/* tuning knobs for A/B measurements in one process: 0 = igemm LDS stage buffers (1|2), 1 = wgrad LDS stage buffers */
+int xr_tune(int knob, int value);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight packing.  Parameters stay fp32 nn.Parameters in the reference layouts
