@@ -499,7 +499,7 @@ constexpr size_t igemm_smem() {
   return ops > stg ? ops : stg;
 }
 
-int g_tune[8] = {1, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm FAST gather path on/off, [1] wgrad LDS buffers (1|2)
+int g_tune[8] = {1, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm FAST gather path on/off, [2] != 0 disables the wgrad FAST path
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
 int launch_igemm_f(IgemmP& p, hipStream_t st);
@@ -570,6 +570,8 @@ struct WgradP {
   float* dwp;
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c;
   FastDiv fd_howo, fd_wo;
+  int a64, b64, c64;            // 64 pixels = a64 images + b64 rows + c64 columns (per-step cursor advance)
+  unsigned in_bytes, dy_bytes;  // buffer-descriptor extents (FAST path)
 };
 
 // transposing fragment fetch from a [pixel][col] LDS image (pitch bytes): 8 pixels x 1 column per lane
@@ -586,7 +588,10 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int pitch,
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <int MODE, int BR, int BC, bool TR, int NBUF>
+// FAST (forward-gather only): the per-slot pixel cursor (n, ho, wo) is advanced incrementally by the scalar
+// decomposition of 64 pixels instead of being re-derived with two divisions per row per step, and both operands
+// come in through buffer loads whose range check supplies the zero padding.
+template <int MODE, int BR, int BC, bool TR, int NBUF, bool FAST>
 __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int BP = 64;  // pixels per stage
   constexpr int NS = MODE ? 3 : 1;
@@ -620,7 +625,74 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   float y_f[MODE ? NY : 1][8], x_f[MODE ? NX : 1][8];
   uint4 y_u[MODE ? 1 : NY], x_u[MODE ? 1 : NX];
 
+  // ---- FAST path state
+  constexpr int ESZ = (int)sizeof(in_t);
+  int xn[FAST ? NX : 1], xh[FAST ? NX : 1], xw[FAST ? NX : 1];
+  unsigned y_base[FAST ? NY : 1];
+  __amdgpu_buffer_rsrc_t rsX, rsY;
+  if constexpr (FAST) {
+    rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
+    rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NY; ++i)
+      y_base[i] = ycol_ok ? (unsigned)(((yrow0 + (NT / CRY) * i) * p.ldy + r0 + ych * 8) * ESZ) : XR_OOR;
+  }
+  auto init_cursor = [&](int step) {
+    if constexpr (FAST) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int m = step * BP + xrow0 + (NT / CRX) * i;
+        const int n = fdiv(p.fd_howo, m);
+        const int rem = m - n * (int)p.fd_howo.d;
+        const int ho = fdiv(p.fd_wo, rem);
+        xn[i] = n; xh[i] = ho; xw[i] = rem - ho * (int)p.fd_wo.d;
+      }
+    }
+  };
+  auto load_stage_fast = [&](int step) {
+    const int mbase = step * BP;
+    const unsigned ysoff = (unsigned)mbase * (unsigned)(p.ldy * ESZ);
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+      const int m = mbase + yrow0 + (NT / CRY) * i;
+      const unsigned voff = m < p.M ? y_base[i] : XR_OOR;
+      if constexpr (MODE == 1) {
+        const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsY, voff, ysoff, 0);
+        const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsY, voff + 16u, ysoff, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { y_f[i][e] = __uint_as_float(u0[e]); y_f[i][4 + e] = __uint_as_float(u1[e]); }
+      } else {
+        const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rsY, voff, ysoff, 0);
+        y_u[i] = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int hi = xh[i] * p.stride - p.pad + tr_, wi = xw[i] * p.stride - p.pad + ts_;
+      const bool ok = col_ok && xn[i] < p.N && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      const unsigned voff = ok ? (unsigned)((((xn[i] * p.H + hi) * p.W + wi) * p.C + cch) * ESZ) : XR_OOR;
+      if constexpr (MODE == 1) {
+        const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff, 0, 0);
+        const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + 16u, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x_f[i][e] = __uint_as_float(u0[e]); x_f[i][4 + e] = __uint_as_float(u1[e]); }
+      } else {
+        const v4u_t u = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff, 0, 0);
+        x_u[i] = make_uint4(u[0], u[1], u[2], u[3]);
+      }
+      // advance this slot's pixel cursor by 64 pixels
+      int w = xw[i] + p.c64, h = xh[i] + p.b64, n = xn[i] + p.a64;
+      if (w >= p.Wo) { w -= p.Wo; ++h; }
+      if (h >= p.Ho) { h -= p.Ho; ++n; }
+      xw[i] = w; xh[i] = h; xn[i] = n;
+    }
+  };
+
   auto load_stage = [&](int step) {
+    if constexpr (FAST) {
+      load_stage_fast(step);
+      return;
+    }
     const int mbase = step * BP;
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
@@ -719,6 +791,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   };
 
   if (s_begin < s_end) {
+    init_cursor(s_begin);
     if constexpr (NBUF == 2) {
       load_stage(s_begin);
       store_stage(0);
@@ -742,7 +815,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     }
   }
 
+  // each pixel-range slice owns a private [K][Kg] slab: plain coalesced stores (128 B per accumulator row), no
+  // atomics -- the slices are summed by xr_unpack_wgrad while it converts to the parameter layout
   const int lr = lane & 31, lh = lane >> 5;
+  float* slab = p.dwp + (size_t)blockIdx.y * p.K * p.Kg;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -752,21 +828,32 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = r0 + wr0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row < p.K) atomicAdd(p.dwp + (size_t)row * p.Kg + col, acc[i][j][e]);
+        if (row < p.K) slab[(size_t)row * p.Kg + col] = acc[i][j][e];
       }
     }
 }
 
-template <int MODE, int BR, int BC, bool TR, int NBUF>
+template <int MODE, int BR, int BC, bool TR, int NBUF, bool FAST>
 int launch_wgrad_nb(WgradP& p, int split, hipStream_t st);
 
 template <int MODE, int BR, int BC, bool TR>
 int launch_wgrad(WgradP& p, int split, hipStream_t st) {
-  if (MODE == 0 && g_tune[1] == 2) return launch_wgrad_nb<MODE, BR, BC, TR, MODE == 0 ? 2 : 1>(p, split, st);
-  return launch_wgrad_nb<MODE, BR, BC, TR, 1>(p, split, st);
+  const long long esz = MODE ? 4 : 2;
+  const long long in_bytes = (long long)p.N * p.H * p.W * p.C * esz, dy_bytes = (long long)p.M * p.ldy * esz;
+  const bool fast = !TR && g_tune[2] == 0 && in_bytes < (1ll << 31) && dy_bytes < (1ll << 31);
+  p.in_bytes = (unsigned)(in_bytes < (1ll << 31) ? in_bytes : 0x7FFFFFFF);
+  p.dy_bytes = (unsigned)(dy_bytes < (1ll << 31) ? dy_bytes : 0x7FFFFFFF);
+  const int howo = p.Ho * p.Wo;
+  p.a64 = 64 / howo;
+  p.b64 = (64 % howo) / p.Wo;
+  p.c64 = (64 % howo) % p.Wo;
+  if constexpr (!TR) {
+    if (fast) return launch_wgrad_nb<MODE, BR, BC, TR, 1, true>(p, split, st);
+  }
+  return launch_wgrad_nb<MODE, BR, BC, TR, 1, false>(p, split, st);
 }
 
-template <int MODE, int BR, int BC, bool TR, int NBUF>
+template <int MODE, int BR, int BC, bool TR, int NBUF, bool FAST>
 int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
   constexpr int NS = MODE ? 3 : 1;
   constexpr size_t smem = (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64)) * NBUF;
@@ -779,7 +866,7 @@ int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
   if (split > p.steps_total) split = p.steps_total;
   p.steps_per_split = cdiv(p.steps_total, split);
   split = cdiv(p.steps_total, p.steps_per_split);
-  auto kern = wgrad_kernel<MODE, BR, BC, TR, NBUF>;
+  auto kern = wgrad_kernel<MODE, BR, BC, TR, NBUF, FAST>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
@@ -790,7 +877,7 @@ int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_c * tiles_r), (unsigned)split), dim3(NT), smem, st, p);
   XR_CHECK_LAUNCH("xr_conv_wgrad");
-  return XR_OK;
+  return split;  // number of slabs written (>= 1)
 }
 
 // ------------------------------------------------------------------------------------------------ pack / unpack
@@ -816,7 +903,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __rest
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ dst, int A2, int taps, int B,
                                     int Bp, int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate,
-                                    int64_t total) {
+                                    int nslices, int64_t slice_stride, int64_t total) {
   // iterate over destination-meaningful elements (a, tap, b)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i % B);
@@ -824,9 +911,9 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __r
     const int tp = (int)(r % taps);
     const int64_t a = r / taps;
     const int64_t a1 = a / A2, a2 = a - a1 * A2;
-    float* src = const_cast<float*>(packed) + a * Kg + (int64_t)tp * Bp + b;
-    const float v = *src;
-    if (accumulate & 2) *src = 0.f;  // read-and-clear: the slab is ready for the next step's atomics
+    const float* src = packed + a * Kg + (int64_t)tp * Bp + b;
+    float v = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) v += src[sl * slice_stride];
     float* d = dst + a1 * sa1 + a2 * sa2 + tp * st_ + b * sb;
     *d = (accumulate & 1) ? (*d + v) : v;
   }
@@ -877,14 +964,15 @@ extern "C" int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, 
 }
 
 extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,
-                               int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate, void* stream) {
-  XR_CHECK_ARG(packed && dst, "xr_unpack_wgrad: null pointer");
+                               int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate, int nslices,
+                               void* stream) {
+  XR_CHECK_ARG(packed && dst && nslices >= 1, "xr_unpack_wgrad: null pointer / nslices < 1");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Kg >= taps * Bp, "xr_unpack_wgrad: bad dims");
   const int64_t total = (int64_t)A1 * A2 * taps * B;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, dst, A2, taps, B, Bp,
-                     Kg, sa1, sa2, st_, sb, accumulate, total);
+                     Kg, sa1, sa2, st_, sb, accumulate, nslices, (int64_t)A1 * A2 * Kg, total);
   XR_CHECK_LAUNCH("xr_unpack_wgrad");
   return XR_OK;
 }
@@ -933,7 +1021,7 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
                ldy);
   XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_wgrad: bad Kg=%d", Kg);
   XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
-  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, {}, {}};
+  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool tall = K > 64;
   if (dtype == XR_BF16) {

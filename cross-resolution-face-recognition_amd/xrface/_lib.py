@@ -77,7 +77,7 @@ class _Lib:
 
         def call(*args):
             rc = fn(*args)
-            if rc != 0:
+            if rc < 0:
                 raise RuntimeError(f"{name} failed ({rc}): {dll.xr_last_error().decode()}")
             return rc
 

@@ -13,7 +13,8 @@ from torch.autograd import Function
 from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, XR_BF16, XR_F32, dt, lib, ptr, stream
 
 EPS = 1e-5
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": 1024}
+import os as _os
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512"))}
 
 
 def set_compute_dtype(dtype):
@@ -92,25 +93,19 @@ def _direct_done(p):
         hook(p)
 
 
-def _wslab(w, K, kg):
-    """Persistent, always-zero-between-steps fp32 slab [K][kg] for the weight-gradient atomics (the unpack kernel
-    reads AND clears it)."""
-    slab = w.__dict__.get("_xr_slab")
-    if slab is None or slab.shape != (K, kg) or slab.device != w.device:
-        slab = torch.zeros((K, kg), dtype=torch.float32, device=w.device)
-        w.__dict__["_xr_slab"] = slab
-    return slab
-
-
-def _emit_wgrad(w, slab, A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb):
-    """slab -> gradient in the parameter's own layout; direct accumulation into w.grad when enabled."""
+def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg, split, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
+    """Weight gradient: sliced implicit GEMM into per-slice slabs, then sum + convert to the parameter layout
+    (accumulating straight into ``w.grad`` when direct mode is on)."""
+    slabs = torch.empty((split, K, kg), dtype=torch.float32, device=x.device)
+    ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg,
+                           split, stream())
     tgt = _direct(w)
     if tgt is not None:
-        lib.xr_unpack_wgrad(ptr(slab), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 3, stream())
+        lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, stream())
         _direct_done(w)
         return None
     dw = torch.empty_like(w, dtype=torch.float32)
-    lib.xr_unpack_wgrad(ptr(slab), ptr(dw), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 2, stream())
+    lib.xr_unpack_wgrad(ptr(slabs), ptr(dw), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 0, ns, stream())
     return dw
 
 
@@ -157,7 +152,7 @@ def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
 def _wgrad_split(M, K, kg):
     tiles = ((K + 127) // 128) * ((kg + 127) // 128) if K > 64 else ((kg + 255) // 256)
     steps = (M + 63) // 64
-    return max(1, min(steps, _cfg["wgrad_blocks"] // max(tiles, 1)))
+    return max(1, min(steps, _cfg["wgrad_blocks"] // max(tiles, 1), 256))
 
 
 # ------------------------------------------------------------------------------------------------- layout
@@ -283,10 +278,8 @@ class _Conv2d(Function):
                               kg, Cp, None, 0, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
-            dwp = _wslab(w, K, kg)
-            lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg,
-                              _wgrad_split(N * Ho * Wo, K, kg), stream())
-            dw = _emit_wgrad(w, dwp, K, 1, R * S, C, Cp, kg, C * R * S, 0, 1, R * S)
+            dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
+                        K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db, None, None
@@ -335,10 +328,8 @@ class _ConvTranspose2d(Function):
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
             kg = kg_of(R * S, Cp)
-            dwp = _wslab(w, Cout, kg)
-            lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1, Kp, kg,
-                              _wgrad_split(N * Ho * Wo, Cout, kg), stream())
-            dw = _emit_wgrad(w, dwp, Cout, 1, R * S, Cin, Cp, kg, R * S, 0, 1, Cout * R * S)
+            dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1, Kp, kg,
+                        _wgrad_split(N * Ho * Wo, Cout, kg), Cout, 1, R * S, Cin, Cp, R * S, 0, 1, Cout * R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, Cout))
         return dx, dw, db, None, None, None
@@ -392,9 +383,7 @@ class _LinearNHWC(Function):
                               HW * C, None, 0, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
-            dwp = _wslab(w, K, kg)
-            lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(dwp), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, stream())
-            dw = _emit_wgrad(w, dwp, K, 1, HW, C, C, kg, C * HW, 0, 1, HW)
+            dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db

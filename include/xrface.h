@@ -81,18 +81,18 @@ int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, v
 int xr_bias_cast(int dtype, const float* ws, const float* bias, void* out, int64_t M, int K, int ld, void* stream);
 
 /* Weight gradient (aten::convolution_backward weight part; same call sites as above).
- * dwp[k][t*C + c] += sum_m dy[m][k] * gather(in)[m][t][c]      (fp32, PACKED layout [K][Kg], atomics;
- * the caller zeroes dwp) where m runs over the N*Ho*Wo pixels of dy (row pitch ldy) and gather()
- * is the same (transposed) tap gather as xr_conv_igemm on `in` [N][H][W][C].
- * split = number of pixel-range splits (>= 1) the reduction is spread over. */
+ * slab[s][k][t*C + c] = sum_{m in slice s} dy[m][k] * gather(in)[m][t][c]   (fp32, PACKED layout [K][Kg])
+ * where m runs over the N*Ho*Wo pixels of dy (row pitch ldy), split into `split` contiguous slices, and gather()
+ * is the same (transposed) tap gather as xr_conv_igemm on `in` [N][H][W][C].  Every slice writes its own slab with
+ * plain stores (no atomics, no zero-init): dwp must hold split*K*Kg floats.
+ * RETURNS the number of slabs written (1 <= value <= split) on success, a negative XR_E_* on failure. */
 int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,
                   int Wo, int K, int R, int S, int stride, int pad, int transposed, int ldy, int Kg, int split,
                   void* stream);
-/* Inverse of xr_pack_weight for gradients: dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= packed[a][t*Bp + b].
- * accumulate bit 0: add into dst instead of overwriting; bit 1: zero the packed slab after reading
- * (read-and-clear, so a persistent slab needs no memset before the next step's atomics). */
+/* Sum the `nslices` slabs and convert to the parameter layout (inverse of xr_pack_weight):
+ * dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= sum_s packed[s][a][t*Bp + b];  accumulate != 0 adds into dst. */
 int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,
-                    int64_t sa1, int64_t sa2, int64_t st, int64_t sb, int accumulate, void* stream);
+                    int64_t sa1, int64_t sa2, int64_t st, int64_t sb, int accumulate, int nslices, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Normalisation / activation family.  Tensors are [G][rows][C] (G groups of `rows` pixels):

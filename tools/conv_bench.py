@@ -43,12 +43,13 @@ def main():
         dx = torch.empty_like(x)
         pk, kg = ops._packed(w, "fwd", dtype, K, 1, 9, C, C, C * 9, 0, 1, 9)
         pkd, kgd = ops._packed(w, "dgrad", dtype, C, 1, 9, K, K, 9, 0, 1, C * 9)
-        slab = torch.zeros(K, kg, device=dev)
+        split = ops._wgrad_split(N * Ho * Ho, K, kg)
+        slab = torch.zeros(split, K, kg, device=dev)
         split = ops._wgrad_split(N * Ho * Ho, K, kg)
         flops = 2.0 * N * Ho * Ho * K * C * 9
         row = f"{C:3d}->{K:3d} @{H:3d} s{st} {flops/1e9:6.1f}GF "
         for v in variants:
-            lib.xr_tune(0, v[0]); lib.xr_tune(1, v[1])
+            lib.xr_tune(0, v[0]); lib.xr_tune(2, 1 - v[1])
             f = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, stream()))
             d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, stream()))
             g = timeit(lambda: lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slab), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, K, kg, split, stream()))
