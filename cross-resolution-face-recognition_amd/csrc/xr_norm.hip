@@ -427,6 +427,132 @@ __global__ __launch_bounds__(NT) void se_excite_bwd_kernel(const float* __restri
   }
 }
 
+// ---- fused BatchNorm -> SE -> (+shortcut) tail of bottleneck_IR_SE (model_irse.py:76-91) ---------------------------
+// With r = a*y + b (BatchNorm as a per-channel affine) the SE squeeze is pooled_r = a*mean_hw(y) + b, so r is never
+// materialised: out = y*(a*s) + (b*s) + shortcut.  Forward kernel: one block per image.
+__global__ __launch_bounds__(NT) void bnse_fwd_kernel(const float* __restrict__ sum_y, const float* __restrict__ a,
+                                                      const float* __restrict__ b, const float* __restrict__ w1,
+                                                      const float* __restrict__ w2, float* __restrict__ pooled_r_sum,
+                                                      float* __restrict__ hidden, float* __restrict__ s,
+                                                      float* __restrict__ coefA, float* __restrict__ coefB, int C, int Cr,
+                                                      float hw) {
+  extern __shared__ float lds[];  // pooled[C] + hid[Cr]
+  float* pooled = lds;
+  float* hid = lds + C;
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int c = t; c < C; c += NT) {
+    const float ps = a[c] * sum_y[(size_t)n * C + c] + hw * b[c];
+    pooled_r_sum[(size_t)n * C + c] = ps;
+    pooled[c] = ps / hw;
+  }
+  __syncthreads();
+  for (int j = wave; j < Cr; j += NT / 64) {
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) v += w1[(size_t)j * C + c] * pooled[c];
+    v = wave_sum(v);
+    if (lane == 0) {
+      v = v > 0.f ? v : 0.f;
+      hid[j] = v;
+      hidden[(size_t)n * Cr + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += NT) {
+    float v = 0.f;
+    for (int j = 0; j < Cr; ++j) v += w2[(size_t)c * Cr + j] * hid[j];
+    const float sv = 1.f / (1.f + __expf(-v));
+    s[(size_t)n * C + c] = sv;
+    coefA[(size_t)n * C + c] = a[c] * sv;
+    coefB[(size_t)n * C + c] = b[c] * sv;
+  }
+}
+
+// backward, per image: ds = sum_hw dout*r = a*S2 + b*S1 -> excitation backward -> dp (gradient every pixel of r gets
+// through the squeeze path)
+__global__ __launch_bounds__(NT) void bnse_bwd_excite_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                             const float* __restrict__ a, const float* __restrict__ b,
+                                                             const float* __restrict__ w1, const float* __restrict__ w2,
+                                                             const float* __restrict__ hidden, const float* __restrict__ s,
+                                                             float* __restrict__ dpre2, float* __restrict__ dhid,
+                                                             float* __restrict__ dp, int C, int Cr, float hw) {
+  extern __shared__ float lds[];  // d2[C] + dh[Cr]
+  float* d2 = lds;
+  float* dh = lds + C;
+  const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  for (int c = t; c < C; c += NT) {
+    const size_t i = (size_t)n * C + c;
+    const float ds = a[c] * S2[i] + b[c] * S1[i];
+    const float sv = s[i];
+    const float v = ds * sv * (1.f - sv);
+    d2[c] = v;
+    dpre2[i] = v;
+  }
+  __syncthreads();
+  for (int j = wave; j < Cr; j += NT / 64) {
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) v += w2[(size_t)c * Cr + j] * d2[c];
+    v = wave_sum(v);
+    if (lane == 0) {
+      v = hidden[(size_t)n * Cr + j] > 0.f ? v : 0.f;
+      dh[j] = v;
+      dhid[(size_t)n * Cr + j] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = t; c < C; c += NT) {
+    float v = 0.f;
+    for (int j = 0; j < Cr; ++j) v += w1[(size_t)j * C + c] * dh[j];
+    dp[(size_t)n * C + c] = v / hw;
+  }
+}
+
+// backward, per channel: BatchNorm sums of d_r = dout*s + dp folded from the per-image sums, then the coefficients of
+// dy = cA[n,c]*dout + cB[c]*y + cC[n,c].  One wave per channel (lanes stride over n).
+__global__ __launch_bounds__(NT) void bnse_bwd_coeffs_kernel(const float* __restrict__ S1, const float* __restrict__ S2,
+                                                             const float* __restrict__ s, const float* __restrict__ dp,
+                                                             const float* __restrict__ sum_y, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ a_eval, float* __restrict__ coef,
+                                                             float* dgamma, float* dbeta, int N, int C, float hw, int train) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float t1 = 0.f, t2 = 0.f;
+  for (int n = lane; n < N; n += 64) {
+    const size_t i = (size_t)n * C + c;
+    t1 += s[i] * S1[i] + hw * dp[i];
+    t2 += s[i] * S2[i] + dp[i] * sum_y[i];
+  }
+  t1 = wave_sum(t1);
+  t2 = wave_sum(t2);
+  const float ga = gamma ? gamma[c] : 1.f;
+  const float mu = mean[c], is = invstd[c];
+  const float t2hat = is * (t2 - mu * t1);
+  float Abn, Bbn, Cbn;
+  if (train) {
+    const float ntot = (float)N * hw;
+    const float m1 = t1 / ntot, m2 = t2hat / ntot;
+    Abn = ga * is;
+    Bbn = -ga * is * is * m2;
+    Cbn = -Abn * m1 - Bbn * mu;
+  } else {
+    Abn = a_eval[c];
+    Bbn = 0.f;
+    Cbn = 0.f;
+  }
+  const size_t NC = (size_t)N * C;
+  for (int n = lane; n < N; n += 64) {
+    const size_t i = (size_t)n * C + c;
+    coef[i] = Abn * s[i];
+    coef[NC + i] = Bbn;
+    coef[2 * NC + i] = Abn * dp[i] + Cbn;
+  }
+  if (lane == 0) {
+    if (dgamma) dgamma[c] += t2hat;
+    if (dbeta) dbeta[c] += t1;
+  }
+}
+
 // out[i][j] += scale * sum_n A[n][i] * B[n][j]   (tiny outer-product accumulation): blockIdx.y slices the n range,
 // 8 independent partial sums per thread keep loads in flight, one atomic per (output, slice)
 __global__ void small_atb_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out, int N,
@@ -564,6 +690,34 @@ extern "C" int xr_se_excite_bwd(const float* w1, const float* w2, const float* h
   hipLaunchKernelGGL(se_excite_bwd_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, w1, w2, hidden, s,
                      ds, dpre2, dhid, dpooled, C, Cr, inv_hw);
   XR_CHECK_LAUNCH("xr_se_excite_bwd");
+  return XR_OK;
+}
+
+extern "C" int xr_bnse_fwd(const float* sum_y, const float* a, const float* b, const float* w1, const float* w2,
+                           float* pooled_r_sum, float* hidden, float* s, float* coefA, float* coefB, int N, int C, int Cr, int HW,
+                           void* stream) {
+  XR_CHECK_ARG(sum_y && a && b && w1 && w2 && pooled_r_sum && hidden && s && coefA && coefB && N > 0 && C > 0 && Cr > 0 &&
+                   C <= 4096 && HW > 0,
+               "xr_bnse_fwd: bad arguments");
+  hipLaunchKernelGGL(bnse_fwd_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, sum_y, a, b, w1, w2,
+                     pooled_r_sum, hidden, s, coefA, coefB, C, Cr, (float)HW);
+  XR_CHECK_LAUNCH("xr_bnse_fwd");
+  return XR_OK;
+}
+
+extern "C" int xr_bnse_bwd(const float* S1, const float* S2, const float* sum_y, const float* a, const float* b,
+                           const float* w1, const float* w2, const float* hidden, const float* s, const float* gamma,
+                           const float* mean, const float* invstd, float* dpre2, float* dhid, float* dp, float* coef,
+                           float* dgamma, float* dbeta, int N, int C, int Cr, int HW, int train, void* stream) {
+  XR_CHECK_ARG(S1 && S2 && sum_y && a && b && w1 && w2 && hidden && s && mean && invstd && dpre2 && dhid && dp && coef &&
+                   N > 0 && C > 0 && Cr > 0 && C <= 4096 && HW > 0,
+               "xr_bnse_bwd: bad arguments");
+  hipLaunchKernelGGL(bnse_bwd_excite_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, S1, S2, a, b, w1,
+                     w2, hidden, s, dpre2, dhid, dp, C, Cr, (float)HW);
+  XR_CHECK_LAUNCH("xr_bnse_bwd(excite)");
+  hipLaunchKernelGGL(bnse_bwd_coeffs_kernel, dim3(cdiv(C, NT / 64)), dim3(NT), 0, (hipStream_t)stream, S1, S2, s, dp, sum_y,
+                     gamma, mean, invstd, a, coef, dgamma, dbeta, N, C, (float)HW, train);
+  XR_CHECK_LAUNCH("xr_bnse_bwd(coeffs)");
   return XR_OK;
 }
 

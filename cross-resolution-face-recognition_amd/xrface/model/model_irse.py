@@ -90,8 +90,8 @@ class bottleneck_IR_SE(bottleneck_IR):
     def f(self, x):
         sc = self._shortcut(x)
         rl = self.res_layer
-        r = rl[4].f(rl[3].f(rl[2].f(rl[1].f(rl[0].f(x)))))
-        return rl[5].f(r, sc)
+        y2 = rl[3].f(rl[2].f(rl[1].f(rl[0].f(x))))
+        return ops.bn_se_add(y2, rl[4], rl[5], sc)   # BatchNorm + SE + shortcut add in one elementwise pass
 
 
 class Bottleneck(namedtuple('Block', ['in_channel', 'depth', 'stride'])):

@@ -584,6 +584,106 @@ def se_scale_add(r, w1, w2, shortcut=None):
     return _SEScaleAdd.apply(r, w1, w2, shortcut)
 
 
+class _BnSeAdd(Function):
+    """out = SE(BatchNorm(y)) + shortcut with BatchNorm(y) never written to HBM (tail of bottleneck_IR_SE,
+    model_irse.py:76-91): one per-image statistics pass over y serves both the batch statistics and the SE squeeze,
+    then a single elementwise pass out = y*(a*s) + (b*s) + shortcut.  Backward is one reduction pass + one apply pass."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, rmean, rvar, w1, w2, shortcut, training, momentum, eps):
+        y = _c(y)
+        N, H, W, C = y.shape
+        HW, Cr = H * W, w1.shape[0]
+        dev = y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        sums_n = zeros_f32((2, N, C), dev)
+        lib.xr_group_stats(dt(y), ptr(y), ptr(sums_n), N, HW, C, stream())
+        gm, bt = _c(gamma.detach().float()), _c(beta.detach().float())
+        mean, invstd = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
+        a, b = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
+        if training:
+            sums = torch.empty((2, 1, C), **f32)
+            lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, N, C, 0, stream())
+            lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(a), ptr(b), ptr(rmean), ptr(rvar), 1,
+                                 N * HW, C, eps, momentum, stream())
+        else:
+            lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(a), ptr(b), C, eps, stream())
+            mean = rmean.detach().float().reshape(1, C)
+            invstd = torch.rsqrt(rvar.detach().float() + eps).reshape(1, C)
+        w1f, w2f = _c(w1.detach().float()), _c(w2.detach().float())
+        pooled = torch.empty((N, C), **f32)
+        hidden, s = torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
+        cA, cB = torch.empty((N, C), **f32), torch.empty((N, C), **f32)
+        lib.xr_bnse_fwd(ptr(sums_n[0]), ptr(a), ptr(b), ptr(w1f), ptr(w2f), ptr(pooled), ptr(hidden), ptr(s), ptr(cA), ptr(cB), N, C,
+                        Cr, HW, stream())
+        sc = None if shortcut is None else _c(shortcut)
+        out = torch.empty_like(y)
+        lib.xr_affine_act(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), N, HW, C, 1, stream())
+        ctx.save_for_backward(y, sums_n, a, b, mean, invstd, gm, w1f, w2f, pooled, hidden, s)
+        ctx.meta = (training, shortcut is not None)
+        ctx.prefs = (gamma, beta, w1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, sums_n, a, b, mean, invstd, gm, w1f, w2f, pooled, hidden, s = ctx.saved_tensors
+        training, has_sc = ctx.meta
+        p_g, p_b, w1, w2 = ctx.prefs
+        dout = _c(dout)
+        if dout.dtype != y.dtype:
+            dout = dout.to(y.dtype)
+        N, H, W, C = y.shape
+        HW, Cr = H * W, hidden.shape[1]
+        dev = y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        red = zeros_f32((3, N, C), dev)  # red[0] = S1 = sum dout, red[1] = S2 = sum dout*y   (per image)
+        lib.xr_affine_act_bwd_reduce(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(red), N, HW, C, 1, stream())
+        dpre2, dhid, dp = torch.empty((N, C), **f32), torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
+        coef = torch.empty((3, N, C), **f32)
+        t_g, t_b = _direct(p_g), _direct(p_b)
+        need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        dgamma = (t_g if t_g is not None else zeros_f32((C,), dev)) if need_g else None
+        dbeta = (t_b if t_b is not None else zeros_f32((C,), dev)) if need_b else None
+        lib.xr_bnse_bwd(ptr(red[0]), ptr(red[1]), ptr(sums_n[0]), ptr(a), ptr(b), ptr(w1f), ptr(w2f), ptr(hidden), ptr(s), ptr(gm),
+                        ptr(mean), ptr(invstd), ptr(dpre2), ptr(dhid), ptr(dp), ptr(coef), ptr(dgamma), ptr(dbeta), N, C, Cr, HW,
+                        int(training), stream())
+        if t_g is not None and need_g:
+            dgamma = None
+            _direct_done(p_g)
+        if t_b is not None and need_b:
+            dbeta = None
+            _direct_done(p_b)
+        dy = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty_like(y)
+            lib.xr_affine_act_bwd_apply(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(coef), ptr(dy), None, N, HW,
+                                        C, 1, stream())
+        dw1 = dw2 = None
+        if ctx.needs_input_grad[5]:
+            t1, t2 = _direct(w1), _direct(w2)
+            dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), dev)
+            dw2 = t2 if t2 is not None else zeros_f32((C, Cr, 1, 1), dev)
+            lib.xr_small_atb(ptr(dhid), ptr(pooled), ptr(dw1), N, Cr, C, 1.0 / HW, 1, stream())
+            lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 1, stream())
+            if t1 is not None:
+                dw1 = None
+                _direct_done(w1)
+            if t2 is not None:
+                dw2 = None
+                _direct_done(w2)
+        return dy, dgamma, dbeta, None, None, dw1, dw2, (dout if has_sc else None), None, None, None
+
+
+def bn_se_add(y, bn, se, shortcut):
+    """bn: an xrface.nn.BatchNorm2d holder, se: a model_irse.SEModule holder."""
+    training = bn.training or not bn.track_running_stats
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return _BnSeAdd.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, se.fc1.weight, se.fc2.weight, shortcut, training,
+                          mom, bn.eps)
+
+
 # ------------------------------------------------------------------------------------------------- resampling
 class _Subsample(Function):
     @staticmethod

@@ -151,6 +151,20 @@ int xr_se_excite_fwd(const float* pooled_sum, const float* w1, const float* w2, 
                      int N, int C, int Cr, float inv_hw, void* stream);
 int xr_se_excite_bwd(const float* w1, const float* w2, const float* hidden, const float* s, const float* ds,
                      float* dpre2, float* dhid, float* dpooled, int N, int C, int Cr, float inv_hw, void* stream);
+/* Fused BatchNorm -> SE -> +shortcut tail of bottleneck_IR_SE (model_irse.py:76-91).  With r = a*y + b the squeeze is
+ * a*mean(y) + b, so r is never materialised: out = y*coefA[n][c] + coefB[n][c] + shortcut (xr_affine_act).
+ * fwd: sum_y [N][C] per-image sums of y (xr_group_stats); a/b [C] the BatchNorm scale/shift;
+ *      outputs pooled_r_sum, hidden [N][Cr], s, coefA = a*s, coefB = b*s (all [N][C] unless noted).
+ * bwd: S1 = sum_hw dout, S2 = sum_hw dout*y per image (xr_affine_act_bwd_reduce);  outputs dpre2 / dhid (for the SE
+ *      weight gradients via xr_small_atb), dp, and coef [3][N][C] such that dy = coef0*dout + coef1*y + coef2
+ *      (xr_affine_act_bwd_apply); dgamma/dbeta (optional) are accumulated.  train = 0: frozen statistics. */
+int xr_bnse_fwd(const float* sum_y, const float* a, const float* b, const float* w1, const float* w2,
+                float* pooled_r_sum, float* hidden, float* s, float* coefA, float* coefB, int N, int C, int Cr, int HW,
+                void* stream);
+int xr_bnse_bwd(const float* S1, const float* S2, const float* sum_y, const float* a, const float* b,
+                const float* w1, const float* w2, const float* hidden, const float* s, const float* gamma,
+                const float* mean, const float* invstd, float* dpre2, float* dhid, float* dp, float* coef,
+                float* dgamma, float* dbeta, int N, int C, int Cr, int HW, int train, void* stream);
 /* out[i][j] (+)= scale * sum_n A[n][i]*B[n][j]  -- dW1 = dhid^T pooled, dW2 = dpre2^T hidden */
 int xr_small_atb(const float* A, const float* B, float* out, int N, int I, int J, float scale, int accumulate,
                  void* stream);
