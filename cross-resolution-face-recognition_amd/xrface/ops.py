@@ -426,12 +426,16 @@ class _NormAct(Function):
         mean = invstd = scale = shift = None
         # BatchNorm sums are taken per image (few blocks per atomic address) and folded over the batch afterwards
         per_img = mode != "in" and N > 1 and H * W >= 16
+        pg = 1
+        if per_img:  # pseudo-groups: the largest divisor of N that is <= 32
+            pg = max(d for d in range(1, min(N, 32) + 1) if N % d == 0)
+            per_img = pg > 1
         if stats:
             if per_img:
-                sums_n = zeros_f32((2, N, C), dev)
-                lib.xr_group_stats(dt(x), ptr(x), ptr(sums_n), N, H * W, C, stream())
+                sums_n = zeros_f32((2, pg, C), dev)
+                lib.xr_group_stats(dt(x), ptr(x), ptr(sums_n), pg, (N // pg) * H * W, C, stream())
                 sums = torch.empty((2, 1, C), **f32)
-                lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, N, C, 0, stream())
+                lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, pg, C, 0, stream())
             else:
                 sums = zeros_f32((2, G, C), dev)
                 lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
@@ -449,7 +453,7 @@ class _NormAct(Function):
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, gm, al, rmean, rvar)
         ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
         ctx.prefs = (gamma, beta, alpha)
-        ctx.per_img = (per_img, N, H * W)
+        ctx.per_img = (per_img, pg, (N // pg) * H * W)
         return y
 
     @staticmethod
