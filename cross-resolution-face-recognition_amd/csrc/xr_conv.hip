@@ -53,6 +53,11 @@ struct IgemmP {
   int ksplit;         // K-stages per blockIdx.y slice (split-K), 0 = no split
   FastDiv fd_howo, fd_wo, fd_c, fd_s, fd_hqwq, fd_wq, fd_tn, fd_st;
   unsigned in_bytes, w_bytes;  // buffer-descriptor extents (FAST path)
+  // fused PReLU backward in the epilogue (dgrad of conv(prelu(y))): out = acc * (y > 0 ? 1 : alpha[c]),
+  // dalpha[c] += sum acc * y * [y <= 0];  ep_src = y laid out like `out`
+  const void* ep_src;
+  const float* ep_alpha;
+  float* ep_dalpha;
 };
 
 // decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
@@ -462,6 +467,12 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
   out_t* __restrict__ out = reinterpret_cast<out_t*>(p.out);
   constexpr int CPR = BN / 8;  // chunks per tile row
   const int Kw = (p.K + 7) & ~7;
+  const bool ep = p.ep_src != nullptr;   // requires K % 8 == 0 (checked by the host)
+  const out_t* __restrict__ ep_src = reinterpret_cast<const out_t*>(p.ep_src);
+  float dal[8], alv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dal[e] = 0.f, alv[e] = 0.f;
+  if (ep && n0 + (t % CPR) * 8 < p.K) ld8(p.ep_alpha + n0 + (t % CPR) * 8, alv);
   for (int idx = t; idx < BM * CPR; idx += NT) {
     const int row = idx / CPR, ch = idx - row * CPR;
     const int ncol = n0 + ch * 8;
@@ -477,6 +488,19 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
     if (m < 0) continue;
     const out_t* sp = stage + row * PITCH + ch * 8;
     out_t* dp = out + (size_t)m * p.ldo + ncol;
+    if (ep) {
+      float d[8], yv[8], o[8];
+      ld8(sp, d);
+      ld8(ep_src + (size_t)m * p.ldo + ncol, yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool neg = yv[e] <= 0.f;
+        o[e] = neg ? d[e] * alv[e] : d[e];
+        if (neg) dal[e] += d[e] * yv[e];
+      }
+      st8(dp, o);
+      continue;
+    }
     if (ncol + 8 <= Kw) {
       if constexpr (sizeof(out_t) == 2) {
         *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
@@ -486,6 +510,18 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
       }
     } else {
       for (int e = 0; e < 8 && ncol + e < Kw; ++e) dp[e] = sp[e];
+    }
+  }
+  if (ep) {  // fold the per-thread dalpha partials: threads sharing a chunk column are CPR apart
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(t / CPR) * BN + (t % CPR) * 8 + e] = dal[e];
+    __syncthreads();
+    for (int c = t; c < BN; c += NT) {
+      float sum = 0.f;
+      for (int r = 0; r < NT / CPR; ++r) sum += red[r * BN + c];
+      if (n0 + c < p.K) atomicAdd(p.ep_dalpha + n0 + c, sum);
     }
   }
 }
@@ -979,8 +1015,11 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
 
 extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
-                             int transposed, int Kg, int ldo, float* splitk_ws, int splitk, void* stream) {
+                             int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
+                             const float* ep_alpha, float* ep_dalpha, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
+  XR_CHECK_ARG(ep_src == nullptr || (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
+               "xr_conv_igemm: fused PReLU-backward epilogue needs alpha, dalpha, K %% 8 == 0, no bias, no split-K");
   XR_CHECK_ARG((splitk_ws == nullptr) == (splitk <= 1), "xr_conv_igemm: split-K needs both a workspace and splitk > 1");
   XR_CHECK_ARG(in && w && (out || splitk_ws), "xr_conv_igemm: null pointer");
   XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
@@ -999,7 +1038,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha};
   hipStream_t st = (hipStream_t)stream;
   const bool wide = K > 64;
   if (dtype == XR_BF16) {

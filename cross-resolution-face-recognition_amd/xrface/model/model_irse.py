@@ -61,6 +61,13 @@ class bottleneck_IR(Module):
             Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False), PReLU(depth),
             Conv2d(depth, depth, (3, 3), stride, 1, bias=False), BatchNorm2d(depth))
 
+    def _conv_prelu_conv(self, x):
+        """BN -> conv3x3 -> PReLU -> conv3x3(stride); the PReLU backward rides in the second conv's dgrad epilogue."""
+        rl = self.res_layer
+        y1 = rl[1].f(rl[0].f(x))
+        c2 = rl[3]
+        return ops.prelu_conv2d(y1, rl[2].weight, c2.weight, c2.stride[0], c2.padding[0])
+
     def _shortcut(self, x):
         if isinstance(self.shortcut_layer, Sequential):
             return self.shortcut_layer[1].f(self.shortcut_layer[0].f(x))
@@ -69,7 +76,7 @@ class bottleneck_IR(Module):
     def f(self, x):
         sc = self._shortcut(x)
         rl = self.res_layer
-        r = rl[3].f(rl[2].f(rl[1].f(rl[0].f(x))))
+        r = self._conv_prelu_conv(x)
         return rl[4].f(r, res=sc)
 
     def forward(self, x):
@@ -90,7 +97,7 @@ class bottleneck_IR_SE(bottleneck_IR):
     def f(self, x):
         sc = self._shortcut(x)
         rl = self.res_layer
-        y2 = rl[3].f(rl[2].f(rl[1].f(rl[0].f(x))))
+        y2 = self._conv_prelu_conv(x)
         return ops.bn_se_add(y2, rl[4], rl[5], sc)   # BatchNorm + SE + shortcut add in one elementwise pass
 
 

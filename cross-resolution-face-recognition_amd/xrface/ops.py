@@ -254,7 +254,7 @@ class _Conv2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, stream())
+                          kg, Kp, None, 0, None, None, None, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -275,7 +275,7 @@ class _Conv2d(Function):
             pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, None, 0, stream())
+                              kg, Cp, None, 0, None, None, None, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
@@ -302,7 +302,7 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
-                          kg, Kp, None, 0, stream())
+                          kg, Kp, None, 0, None, None, None, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -324,7 +324,7 @@ class _ConvTranspose2d(Function):
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
-                              kg, Cp, None, 0, stream())
+                              kg, Cp, None, 0, None, None, None, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
             kg = kg_of(R * S, Cp)
@@ -354,11 +354,11 @@ class _LinearNHWC(Function):
         split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None,
                               stream())
             lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None,
                               stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -380,13 +380,72 @@ class _LinearNHWC(Function):
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
-                              HW * C, None, 0, stream())
+                              HW * C, None, 0, None, None, None, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
             dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db
+
+
+class _PreluConv2d(Function):
+    """y2 = conv2d(prelu(y1, alpha), w)  (bias-free; model_irse.py:59-60).  Forward is the plain two-kernel sequence;
+    backward fuses the PReLU backward into the input-gradient epilogue (no d_prelu round trip through HBM)."""
+
+    @staticmethod
+    def forward(ctx, y1, alpha, w, stride, pad):
+        y1 = _c(y1)
+        N, H, W, Cp = y1.shape
+        K, C, R, S = w.shape
+        assert C == Cp and C % 8 == 0
+        al = _c(alpha.detach().float())
+        p1 = torch.empty_like(y1)
+        lib.xr_affine_act(dt(y1), ptr(y1), None, None, None, ptr(al), ACT_PRELU, ptr(p1), 1, N * H * W, C, 0, stream())
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        pk, kg = _packed(w, "fwd", y1.dtype, K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
+        Kp = r8(K)
+        y2 = torch.empty((N, Ho, Wo, Kp), dtype=y1.dtype, device=y1.device)
+        lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
+                          None, None, None, stream())
+        ctx.save_for_backward(y1, p1, w, al)
+        ctx.geom = (stride, pad)
+        ctx.alpha_ref = alpha
+        return y2
+
+    @staticmethod
+    def backward(ctx, dy):
+        y1, p1, w, al = ctx.saved_tensors
+        stride, pad = ctx.geom
+        alpha = ctx.alpha_ref
+        dy = _c(dy)
+        if dy.dtype != y1.dtype:
+            dy = dy.to(y1.dtype)
+        N, H, W, Cp = y1.shape
+        K, C, R, S = w.shape
+        _, Ho, Wo, Kp = dy.shape
+        dev = y1.device
+        dy1 = dalpha = dw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            t_a = _direct(alpha)
+            dal = t_a if t_a is not None else zeros_f32((C,), dev)
+            pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
+            dy1 = torch.empty_like(y1)
+            lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
+                              0, ptr(y1), ptr(al), ptr(dal), stream())
+            if t_a is not None:
+                _direct_done(alpha)
+            else:
+                dalpha = dal
+        if ctx.needs_input_grad[2]:
+            kg = kg_of(R * S, Cp)
+            dw = _wgrad(w, p1, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
+                        K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
+        return dy1, dalpha, dw, None, None
+
+
+def prelu_conv2d(y1, alpha, w, stride=1, pad=0):
+    return _PreluConv2d.apply(y1, alpha, w, stride, pad)
 
 
 def conv2d(x, w, b=None, stride=1, pad=0):
