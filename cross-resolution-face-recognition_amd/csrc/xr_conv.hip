@@ -141,9 +141,14 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 // C % 64 == 0, so a K-stage is one (tap, 64-channel chunk): per-row byte offsets and per-row tap-validity bitmasks are
 // computed once per tile, the per-stage part is scalar, and out-of-image taps are fetched as zeros by the buffer
 // range check -- ~4 VALU per gathered row per stage instead of ~15.
-template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
-__global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(IgemmP p) {
-  constexpr int NBUF = 1;
+// DMA (bf16 FAST only): both operand tiles go global -> LDS by LDS-DMA (buffer_load ... lds, 16 B per lane, zero fill by
+// the descriptor range check), double-buffered: the copy of stage k+1 runs while the MFMAs consume stage k, and neither
+// VGPRs nor ds_write issue slots (the LDS write port is ~80 B/clk on gfx950) are spent on staging.  The LDS image is
+// lane-linear, so the XOR swizzle is applied to the SOURCE chunk each lane fetches.
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, bool DMA>
+__global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm_kernel(IgemmP p) {
+  constexpr int NBUF = DMA ? 2 : 1;
+  static_assert(!DMA || (FAST && MODE == 0), "DMA staging needs the FAST bf16 path");
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int NS = MODE ? 3 : 1;
@@ -198,8 +203,10 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
     return valid ? (n * p.Ho + ho) * p.Wo + wo : -1;
   };
 
-  const int cc = t & 7;   // 16-B chunk column inside the K-stage
   const int rbase = t >> 3;
+  // 16-B chunk column inside the K-stage this thread fetches; with DMA staging the thread's LDS slot is fixed
+  // (lane-linear image), so it fetches the chunk that the swizzle maps INTO that slot
+  const int cc = DMA ? ((t & 7) ^ ((rbase >> 1) & 7)) : (t & 7);
   bool a_valid[RA];
   int a_nb[RA], a_oh[RA], a_ow[RA];
 #pragma unroll
@@ -282,6 +289,39 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
       st_c0 = 0;
       ++st_ti;
       if (++st_ss == nsw) { st_ss = 0; ++st_rr; }
+    }
+  };
+
+  // LDS-DMA staging of the stage under the cursor into buffer `buf`
+  auto dma_stage = [&](int buf) {
+    if constexpr (DMA) {
+      typedef __attribute__((address_space(3))) void* lds_ptr_t;
+      const int wrow = (t >> 6) * 8;  // first tile row this wave fills (wave-uniform; hipcc broadcasts it for M0)
+      unsigned char* sA = smem + buf * STAGE;
+      unsigned char* sB = sA + BM * 128;
+      int dpix = st_rr * p.W + st_ss;
+      if (TR) dpix = -dpix;
+      const int dby = (dpix * p.C + st_c0) * ESZ;
+      const int wk = cls_mode ? ((r0 + st_rr * p.stride) * p.S + (s0 + st_ss * p.stride)) * p.C + st_c0 : st_ti * p.C + st_c0;
+      const unsigned sh = (unsigned)st_ti;
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass of hipcc does not know that gfx950 allows 16-byte LDS-DMA
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const unsigned voff = ((a_mlo[i] >> sh) & 1u) ? (unsigned)(a_off[i] + dby) : XR_OOR;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + (wrow + 32 * i) * 128), 16, voff, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(sB + (wrow + 32 * i) * 128), 16, b_off[i], wk * 2, 0, 0);
+#else
+      (void)sA; (void)sB; (void)dby; (void)wk; (void)sh; (void)wrow;
+#endif
+      st_c0 += BK;
+      if (st_c0 >= p.C) {
+        st_c0 = 0;
+        ++st_ti;
+        if (++st_ss == nsw) { st_ss = 0; ++st_rr; }
+      }
     }
   };
 
@@ -407,21 +447,20 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
     }
   };
 
-  if constexpr (NBUF == 2) {
-    // stage kk lives in buffer kk&1: loads for kk+1 fly during the MFMAs of kk and are written to the OTHER
-    // buffer afterwards; a single barrier per stage orders both the RAW (next reads) and the WAR (next writes)
-    if (kbeg < nk) {
-      load_stage(kbeg);
-      store_stage(0);
-    }
+  if constexpr (DMA) {
+    // stage kk lives in buffer (kk-kbeg)&1.  The DMA of stage kk+1 into the other buffer is issued before the MFMAs
+    // of stage kk; the barrier (hipcc drains vmcnt(0) in front of it because LDS-DMA is pending) then orders RAW
+    // (next stage's reads) and WAR (the buffer just consumed becomes the next DMA target).
+    if (kbeg < nk) dma_stage(0);
     __syncthreads();
     for (int kk = kbeg; kk < nk; ++kk) {
       const int buf = (kk - kbeg) & 1;
-      if (kk + 1 < nk) load_stage(kk + 1);
+      if (kk + 1 < nk) dma_stage(buf ^ 1);
       compute_stage(buf);
-      if (kk + 1 < nk) store_stage(buf ^ 1);
       __syncthreads();
     }
+  } else if constexpr (NBUF == 2) {
+    __builtin_trap();
   } else {
     if (kbeg < nk) load_stage(kbeg);
     for (int kk = kbeg; kk < nk; ++kk) {
@@ -526,18 +565,18 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0) ? 4 : 1) void igemm_kernel(
   }
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, bool DMA>
 constexpr size_t igemm_smem() {
   constexpr int NS = MODE ? 3 : 1;
-  constexpr size_t ops = (size_t)NS * (BM + BN) * 128;
+  constexpr size_t ops = (size_t)NS * (BM + BN) * 128 * (DMA ? 2 : 1);
   constexpr size_t esz = MODE ? 4 : 2;
   constexpr size_t stg = (size_t)BM * (BN + 16 / esz) * esz;
   return ops > stg ? ops : stg;
 }
 
-int g_tune[8] = {1, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm FAST gather path on/off, [2] != 0 disables the wgrad FAST path
+int g_tune[8] = {3, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA staging, 3 auto; [2] != 0 disables wgrad FAST
 
-template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, bool DMA>
 int launch_igemm_f(IgemmP& p, hipStream_t st);
 
 template <int MODE, int BM, int BN, int WM, bool TR>
@@ -551,11 +590,17 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
                     in_bytes < (1ll << 31) && w_bytes < (1ll << 31) && p.Kg == p.R * p.S * p.C;
   p.in_bytes = (unsigned)(in_bytes < (1ll << 31) ? in_bytes : 0x7FFFFFFF);
   p.w_bytes = (unsigned)(w_bytes < (1ll << 31) ? w_bytes : 0x7FFFFFFF);
-  if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true>(p, st);
-  return launch_igemm_f<MODE, BM, BN, WM, TR, false>(p, st);
+  if constexpr (MODE == 0) {
+    // LDS-DMA staging pays once the K loop is long enough to amortise the lower occupancy (2 x 32 KB stages per WG):
+    // measured cross-over between the 128- and 256-channel 3x3 layers (18 vs 36 stages)
+    const bool dma = g_tune[0] == 2 || (g_tune[0] == 3 && p.Kg / BK >= 32);
+    if (fast && dma) return launch_igemm_f<MODE, BM, BN, WM, TR, true, true>(p, st);
+  }
+  if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true, false>(p, st);
+  return launch_igemm_f<MODE, BM, BN, WM, TR, false, false>(p, st);
 }
 
-template <int MODE, int BM, int BN, int WM, bool TR, bool FAST>
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, bool DMA>
 int launch_igemm_f(IgemmP& p, hipStream_t st) {
   p.tiles_n = cdiv((p.K + 7) / 8 * 8, BN);
   int tiles_m = cdiv(p.M, BM);
@@ -584,8 +629,8 @@ int launch_igemm_f(IgemmP& p, hipStream_t st) {
   } else {
     p.ksplit = 0;
   }
-  constexpr size_t smem = igemm_smem<MODE, BM, BN>();
-  auto kern = igemm_kernel<MODE, BM, BN, WM, TR, FAST>;
+  constexpr size_t smem = igemm_smem<MODE, BM, BN, DMA>();
+  auto kern = igemm_kernel<MODE, BM, BN, WM, TR, FAST, DMA>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);

@@ -48,11 +48,20 @@ def main():
         split = ops._wgrad_split(N * Ho * Ho, K, kg)
         flops = 2.0 * N * Ho * Ho * K * C * 9
         row = f"{C:3d}->{K:3d} @{H:3d} s{st} {flops/1e9:6.1f}GF "
+        ref = None
         for v in variants:
             lib.xr_tune(0, v[0]); lib.xr_tune(2, 1 - v[1])
             f = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None, None, stream()))
             d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None, None, stream()))
             g = timeit(lambda: lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slab), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, K, kg, split, stream()))
+            torch.cuda.synchronize()
+            cur = (y.float().clone(), dx.float().clone())
+            if ref is None:
+                ref = cur
+            else:
+                err = max(float((cur[0] - ref[0]).abs().max()), float((cur[1] - ref[1]).abs().max()))
+                if err != 0.0:
+                    row += f" !!DIFF {err:.3g}"
             for i, tms in enumerate((f, d, g)):
                 tot[v][i] += tms
             row += "   " + "/".join(f"{flops / (tms * 1e-3) / 1e12:6.0f}" for tms in (f, d, g))
