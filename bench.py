@@ -116,10 +116,18 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # XR_REHEARSE=1: multi-rank rehearsal on a ONE-GPU box (every rank on cuda:0, gloo transport) -- exercises the
+    # data-parallel code path, never used for reported numbers
+    rehearse = os.environ.get("XR_REHEARSE", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import xrface
     from xrface import parallel
@@ -153,6 +161,10 @@ def main():
         step(i)
     if world > 1:
         dist.barrier()
+        # replicas must still agree after the warm-up steps (same averaged gradients -> same weights)
+        chk = flat.flat[:4096].clone()
+        dist.broadcast(chk, 0)
+        assert torch.equal(chk, flat.flat[:4096]), "replicas diverged: gradient all-reduce is broken"
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -40,3 +40,19 @@ class CrossEntropyLoss(nn.Module):
 
     def forward(self, input, target):
         return ops.cross_entropy(input, target)
+
+
+class ArcFaceHead(nn.Module):
+    """Build-defined ArcFace margin head (named by BASELINE.json's north_star, absent from the reference tree;
+    l2_norm as in model_irse.py:16-20).  forward(emb, target) -> margin logits (N, classes); pair with
+    CrossEntropyLoss.  Parity is pinned only against this repo's fp64 restatement (oracle/cpu_ref.py:arcface_logits)."""
+
+    def __init__(self, in_features=512, classes=10572, s=64.0, m=0.5):
+        super().__init__()
+        import torch
+        self.weight = nn.Parameter(torch.empty(classes, in_features))
+        nn.init.xavier_uniform_(self.weight)
+        self.s, self.m = s, m
+
+    def forward(self, emb, target):
+        return ops.arcface_logits(emb, self.weight, target, self.s, self.m)

@@ -1048,3 +1048,66 @@ def cross_entropy_2d(pred, target):
 
 def cross_entropy(logits, target):
     return _CERows.apply(logits, target)
+
+
+# ------------------------------------------------------------------------------------------------- ArcFace head
+class _L2NormRows(Function):
+    """y = x / ||x||_2 per row (l2_norm, model_irse.py:16-20); fp32."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = _c(x.float())
+        M, C = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty(M, dtype=torch.float32, device=x.device)
+        lib.xr_l2norm_rows(ptr(x), ptr(y), ptr(inv), M, C, stream())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = _c(dy.float())
+        dx = torch.empty_like(y)
+        lib.xr_l2norm_rows_bwd(ptr(y), ptr(inv), ptr(dy), ptr(dx), y.shape[0], y.shape[1], stream())
+        return dx
+
+
+class _ArcMargin(Function):
+    """logits = s * (phi(cos) at the target column, cos elsewhere), phi = cos(theta + m) with the usual
+    cos(pi - m) fallback (build-defined ArcFace margin)."""
+
+    @staticmethod
+    def forward(ctx, cos, target, s, m):
+        cos = _c(cos.float())
+        M, C = cos.shape
+        out = cos.clone()
+        dphi = torch.ones(M, dtype=torch.float32, device=cos.device)
+        t = _c(target.long())
+        lib.xr_arcface_margin(ptr(out), ptr(t), ptr(dphi), M, C, s, m, stream())
+        ctx.save_for_backward(dphi, t)
+        ctx.s = s
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        dphi, t = ctx.saved_tensors
+        g = dlogits.float() * ctx.s
+        rows = torch.arange(g.shape[0], device=g.device)
+        g[rows, t] = g[rows, t] * dphi  # host-side index fix-up on N elements (plumbing)
+        return g, None, None, None
+
+
+def l2norm_rows(x):
+    return _L2NormRows.apply(x)
+
+
+def arcface_logits(emb, weight, target, s=64.0, m=0.5):
+    """emb (N, D), weight (classes, D) -> (N, classes) fp32 margin logits.  The cosine matrix is an implicit-GEMM
+    launch in XR_F32 mode (3-plane split MFMA) on the row-normalised operands."""
+    e = l2norm_rows(emb)
+    w = l2norm_rows(weight)
+    n, d = e.shape
+    cos = leave2d(linear_nhwc(e.reshape(n, 1, 1, d), w, None))[:, :w.shape[0]]
+    return _ArcMargin.apply(cos, target, float(s), float(m))

@@ -353,3 +353,28 @@ def test_pairdist_and_roc_against_reference_fixture():
     # empty-ish / ragged edge: one pair, one threshold, one fold
     t1, f1, a1, b1 = calculate_roc(np.array([1.0]), e1[:1], e2[:1], same[:1], nrof_folds=1, fold_id=np.zeros(1, np.int32))
     assert t1.shape == (1,) and b1.shape == (1,)
+
+
+def test_arcface_head_against_fp64_restatement():
+    """ArcFace is absent from the reference (parity unpinned): checked against the fp64 restatement in the oracle."""
+    from oracle import cpu_ref as R
+    from xrface.loss.loss import ArcFaceHead, CrossEntropyLoss
+    n, d, classes = 32, 512, 1000
+    emb = rnd("afe", n, d)
+    w = rnd("afw", classes, d, scale=0.05)
+    tgt = G.synth_labels(n, classes)
+    e64, w64 = emb.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = R.arcface_logits(e64, w64, tgt)
+    l_ref = F.cross_entropy(ref, tgt)
+    l_ref.backward()
+    head = ArcFaceHead(d, classes).to(DEV)
+    with torch.no_grad():
+        head.weight.copy_(w.to(DEV))
+    eg = emb.to(DEV).requires_grad_(True)
+    logits = head(eg, tgt.to(DEV))
+    loss = CrossEntropyLoss()(logits, tgt.to(DEV))
+    loss.backward()
+    assert rel(logits, ref) < 2e-4
+    assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
+    assert rel(eg.grad, e64.grad) < 2e-3
+    assert rel(head.weight.grad, w64.grad) < 2e-3
