@@ -65,13 +65,23 @@ def dominant_kernel_roofline(dev, dtype, batch, reps=10):
     ms = e0.elapsed_time(e1) / reps
     flops = 2.0 * N * H * H * K * C * 9
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch of this kernel at this shape come from the committed rocprofv3 PMC passes (FETCH_SIZE x2
+    # gfx950 correction + WRITE_SIZE; profiles/r01_dominant_kernel_pmc.json) -- bench.py cannot run the profiler itself
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")) as f:
+            pmc = json.load(f)
+        if batch == 256:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "kernel": "igemm_kernel<bf16,128x128> conv3x3 256->256 @14x14 fwd", "avg_launch_ms": round(ms, 4),
             "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=12.0):
     """The CPU oracle (oracle/cpu_ref.py: stock torch fp32 CPU ops, the reference's module graph) timed on the
     host cores on a bounded sample of the same workload: IR-SE-50 fwd+bwd at N = 8 per step."""
     from oracle import cpu_ref as R
@@ -93,7 +103,7 @@ def cpu_baseline(budget_s=20.0):
     while True:
         R.teacher_step_grads(sd, x, t, se=True)
         steps += 1
-        if time.perf_counter() - t0 > budget_s or steps >= 30:
+        if time.perf_counter() - t0 > budget_s or steps >= 200:
             break
     el = time.perf_counter() - t0
     return {"value": round(n * steps / el, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",

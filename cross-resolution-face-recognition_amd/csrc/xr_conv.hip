@@ -649,7 +649,7 @@ struct WgradP {
   const void* in;
   const void* dy;
   float* dwp;
-  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c;
+  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c, tiles_all;
   FastDiv fd_howo, fd_wo;
   int a64, b64, c64;            // 64 pixels = a64 images + b64 rows + c64 columns (per-step cursor advance)
   unsigned in_bytes, dy_bytes;  // buffer-descriptor extents (FAST path)
@@ -687,7 +687,15 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int tile_c = blockIdx.x % p.tiles_c, tile_r = blockIdx.x / p.tiles_c;
+  // 1-D grid, XCD-aware order: each XCD gets a contiguous run of (slice, tile) work items, so the tiles of one pixel
+  // slice -- which all re-read the same dY / X rows -- meet in one L2 instead of being dealt over all eight
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int slice = bid / p.tiles_all, tile = bid - slice * p.tiles_all;
+  const int tile_c = tile % p.tiles_c, tile_r = tile / p.tiles_c;
   const int r0 = tile_r * BR, c0 = tile_c * BC;
   const int HW = p.H * p.W;
   const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
@@ -846,7 +854,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int wr0 = (wave / WC) * 64, wc0 = (wave % WC) * 64;
-  const int s_begin = blockIdx.y * p.steps_per_split;
+  const int s_begin = slice * p.steps_per_split;
   int s_end = s_begin + p.steps_per_split;
   if (s_end > p.steps_total) s_end = p.steps_total;
 
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   // each pixel-range slice owns a private [K][Kg] slab: plain coalesced stores (128 B per accumulator row), no
   // atomics -- the slices are summed by xr_unpack_wgrad while it converts to the parameter layout
   const int lr = lane & 31, lh = lane >> 5;
-  float* slab = p.dwp + (size_t)blockIdx.y * p.K * p.Kg;
+  float* slab = p.dwp + (size_t)slice * p.K * p.Kg;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -956,7 +964,8 @@ int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
       return XR_E_LAUNCH;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_c * tiles_r), (unsigned)split), dim3(NT), smem, st, p);
+  p.tiles_all = p.tiles_c * tiles_r;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.tiles_all * split)), dim3(NT), smem, st, p);
   XR_CHECK_LAUNCH("xr_conv_wgrad");
   return split;  // number of slabs written (>= 1)
 }
@@ -1105,7 +1114,7 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
                ldy);
   XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_wgrad: bad Kg=%d", Kg);
   XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
-  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0};
+  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool tall = K > 64;
   if (dtype == XR_BF16) {
