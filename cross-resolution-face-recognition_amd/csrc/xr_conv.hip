@@ -103,6 +103,13 @@ __device__ __forceinline__ bool tap_coord(int oh0, int ow0, int r, int s, int st
 
 // LDS operand image: rows of 64 bf16 (128 B), 16-B chunk index XOR-swizzled by (row>>1)&7
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// same idea for 32-element (64 B) stage rows: 4 chunks per row, swizzled by (row>>2)&3 -> any 16 consecutive rows of
+// one chunk column land on 16 distinct 16-B slots of the 256-B bank row
+template <int BKT>
+__device__ __forceinline__ int lds_off_t(int row, int chunk) {
+  if constexpr (BKT == 64) return lds_off(row, chunk);
+  else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
+}
 
 // fp32 -> NP bf16 planes with x ~= sum_p plane[p] (3 planes carry all 24 significand bits)
 template <int NP>
@@ -145,19 +152,23 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 // the descriptor range check), double-buffered: the copy of stage k+1 runs while the MFMAs consume stage k, and neither
 // VGPRs nor ds_write issue slots (the LDS write port is ~80 B/clk on gfx950) are spent on staging.  The LDS image is
 // lane-linear, so the XOR swizzle is applied to the SOURCE chunk each lane fetches.
-template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, bool DMA>
-__global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm_kernel(IgemmP p) {
-  constexpr int NBUF = DMA ? 2 : 1;
-  static_assert(!DMA || (FAST && MODE == 0), "DMA staging needs the FAST bf16 path");
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT>
+__global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void igemm_kernel(IgemmP p) {
+  constexpr int NBUF = DMA ? DMA : 1;
+  static_assert(DMA == 0 || (FAST && MODE == 0), "DMA staging needs the FAST bf16 path");
+  static_assert(BKT == 64 || (BKT == 32 && DMA != 0), "32-element stages exist for the DMA path only");
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int NS = MODE ? 3 : 1;
-  constexpr int RA = BM / 32, RB = BN / 32;
+  constexpr int CPW = BKT / 8;        // 16-B chunks per stage row
+  constexpr int RPP = NT / CPW;       // tile rows covered by one pass of the 256 threads
+  constexpr int RA = BM / RPP, RB = BN / RPP;
+  constexpr int ROWB = BKT * 2;       // stage row bytes
   using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
   using out_t = in_t;
   constexpr int PADE = 16 / sizeof(out_t);
 
-  constexpr int STAGE = NS * (BM + BN) * 128;        // NBUF == 2 double-buffers the LDS stage (one barrier per stage)
+  constexpr int STAGE = NS * (BM + BN) * ROWB;       // one LDS stage (A rows then B rows)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int t = threadIdx.x;
@@ -203,14 +214,15 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
     return valid ? (n * p.Ho + ho) * p.Wo + wo : -1;
   };
 
-  const int rbase = t >> 3;
+  const int rbase = t / CPW;
   // 16-B chunk column inside the K-stage this thread fetches; with DMA staging the thread's LDS slot is fixed
   // (lane-linear image), so it fetches the chunk that the swizzle maps INTO that slot
-  const int cc = DMA ? ((t & 7) ^ ((rbase >> 1) & 7)) : (t & 7);
+  const int swz = BKT == 64 ? ((rbase >> 1) & 7) : ((rbase >> 2) & 3);
+  const int cc = DMA ? ((t & (CPW - 1)) ^ swz) : (t & (CPW - 1));
   bool a_valid[RA];
   int a_nb[RA], a_oh[RA], a_ow[RA];
 #pragma unroll
-  for (int i = 0; i < RA; ++i) (void)decode_row(rbase + 32 * i, a_valid[i], a_nb[i], a_oh[i], a_ow[i]);
+  for (int i = 0; i < RA; ++i) (void)decode_row(rbase + RPP * i, a_valid[i], a_nb[i], a_oh[i], a_ow[i]);
 
   float a_f[MODE ? RA : 1][8];
   uint4 a_u[MODE ? 1 : RA];
@@ -247,7 +259,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int row = n0 + rbase + 32 * i;
+      const int row = n0 + rbase + RPP * i;
       b_off[i] = row < p.K ? (unsigned)((row * p.Kg + cc * 8) * 2) : XR_OOR;
     }
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, p.in_bytes, 0x00020000);
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
         b_u[q][i] = make_uint4(u[0], u[1], u[2], u[3]);
       }
     // advance the cursor to the next stage
-    st_c0 += BK;
+    st_c0 += BKT;
     if (st_c0 >= p.C) {
       st_c0 = 0;
       ++st_ti;
@@ -296,9 +308,10 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
   auto dma_stage = [&](int buf) {
     if constexpr (DMA) {
       typedef __attribute__((address_space(3))) void* lds_ptr_t;
-      const int wrow = (t >> 6) * 8;  // first tile row this wave fills (wave-uniform; hipcc broadcasts it for M0)
+      constexpr int RPW = 1024 / ROWB;           // stage rows one 1-KiB wave-instruction fills
+      const int wrow = (t >> 6) * RPW;           // first tile row this wave fills (wave-uniform; hipcc broadcasts it for M0)
       unsigned char* sA = smem + buf * STAGE;
-      unsigned char* sB = sA + BM * 128;
+      unsigned char* sB = sA + BM * ROWB;
       int dpix = st_rr * p.W + st_ss;
       if (TR) dpix = -dpix;
       const int dby = (dpix * p.C + st_c0) * ESZ;
@@ -308,15 +321,15 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const unsigned voff = ((a_mlo[i] >> sh) & 1u) ? (unsigned)(a_off[i] + dby) : XR_OOR;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + (wrow + 32 * i) * 128), 16, voff, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + (wrow + RPP * i) * ROWB), 16, voff, 0, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(sB + (wrow + 32 * i) * 128), 16, b_off[i], wk * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr_t)(sB + (wrow + RPP * i) * ROWB), 16, b_off[i], wk * 2, 0, 0);
 #else
       (void)sA; (void)sB; (void)dby; (void)wk; (void)sh; (void)wrow;
 #endif
-      st_c0 += BK;
+      st_c0 += BKT;
       if (st_c0 >= p.C) {
         st_c0 = 0;
         ++st_ti;
@@ -408,37 +421,37 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
 
   const int wm0 = (wave / WN) * (TM * 32), wn0 = (wave % WN) * (TN * 32);
   const int lr = lane & 31, lh = lane >> 5;
-  int nk = cls_mode ? nr * ns * (p.C >> 6) : p.Kg / BK;
+  int nk = cls_mode ? nr * ns * (p.C / BKT) : p.Kg / BKT;
   int kbeg = 0;
   if (p.ksplit > 0) {
     kbeg = blockIdx.y * p.ksplit;
     nk = (kbeg + p.ksplit < nk) ? kbeg + p.ksplit : nk;
   }
   if constexpr (FAST) {
-    const int cpt = p.C >> 6;
+    const int cpt = p.C / BKT;
     st_ti = kbeg / cpt;
-    st_c0 = (kbeg - st_ti * cpt) * BK;
+    st_c0 = (kbeg - st_ti * cpt) * BKT;
     st_rr = st_ti / nsw;
     st_ss = st_ti - st_rr * nsw;
   }
 
   auto compute_stage = [&](int buf) {
     const unsigned char* sA = smem + buf * STAGE;
-    const unsigned char* sB = sA + NS * BM * 128;
+    const unsigned char* sB = sA + NS * BM * ROWB;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < BKT / 16; ++ks) {
       bf16x8_t fa[TM][NS], fb[TN][NS];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int off = lds_off(wm0 + i * 32 + lr, ks * 2 + lh);
+        const int off = lds_off_t<BKT>(wm0 + i * 32 + lr, ks * 2 + lh);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fa[i][s] = *reinterpret_cast<const bf16x8_t*>(sA + s * BM * 128 + off);
+        for (int s = 0; s < NS; ++s) fa[i][s] = *reinterpret_cast<const bf16x8_t*>(sA + s * BM * ROWB + off);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int off = lds_off(wn0 + j * 32 + lr, ks * 2 + lh);
+        const int off = lds_off_t<BKT>(wn0 + j * 32 + lr, ks * 2 + lh);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fb[j][s] = *reinterpret_cast<const bf16x8_t*>(sB + s * BN * 128 + off);
+        for (int s = 0; s < NS; ++s) fb[j][s] = *reinterpret_cast<const bf16x8_t*>(sB + s * BN * ROWB + off);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -447,7 +460,30 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
     }
   };
 
-  if constexpr (DMA) {
+  if constexpr (DMA == 3) {
+    // three-stage ring, two stages in flight: at the top of iteration k this wave waits only for ITS copies of stage k
+    // (counted vmcnt leaves the RA+RB newest = stage k+1 in flight), the raw barrier then makes every wave's stage k
+    // visible and proves stage k-1 fully consumed, so its buffer is handed to the DMA of stage k+2.  No vmcnt(0) and
+    // no __syncthreads() inside the loop (that would drain the in-flight stage).
+    if (kbeg < nk) dma_stage(0);
+    if (kbeg + 1 < nk) dma_stage(1);
+    int buf = 0;
+    for (int kk = kbeg; kk < nk; ++kk) {
+      if (kk + 1 < nk) {
+        if constexpr (RA + RB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      int nbuf = buf + 2;
+      if (nbuf >= 3) nbuf -= 3;
+      if (kk + 2 < nk) dma_stage(nbuf);
+      compute_stage(buf);
+      if (++buf == 3) buf = 0;
+    }
+    __syncthreads();
+  } else if constexpr (DMA == 2) {
     // stage kk lives in buffer (kk-kbeg)&1.  The DMA of stage kk+1 into the other buffer is issued before the MFMAs
     // of stage kk; the barrier (hipcc drains vmcnt(0) in front of it because LDS-DMA is pending) then orders RAW
     // (next stage's reads) and WAR (the buffer just consumed becomes the next DMA target).
@@ -565,10 +601,10 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && !DMA) ? 4 : 1) void igemm
   }
 }
 
-template <int MODE, int BM, int BN, bool DMA>
+template <int MODE, int BM, int BN, int DMA, int BKT>
 constexpr size_t igemm_smem() {
   constexpr int NS = MODE ? 3 : 1;
-  constexpr size_t ops = (size_t)NS * (BM + BN) * 128 * (DMA ? 2 : 1);
+  constexpr size_t ops = (size_t)NS * (BM + BN) * (BKT * 2) * (DMA ? DMA : 1);
   constexpr size_t esz = MODE ? 4 : 2;
   constexpr size_t stg = (size_t)BM * (BN + 16 / esz) * esz;
   return ops > stg ? ops : stg;
@@ -576,7 +612,7 @@ constexpr size_t igemm_smem() {
 
 int g_tune[8] = {3, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA staging, 3 auto; [2] != 0 disables wgrad FAST
 
-template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, bool DMA>
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
 int launch_igemm_f(IgemmP& p, hipStream_t st);
 
 template <int MODE, int BM, int BN, int WM, bool TR>
@@ -594,13 +630,15 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
     // LDS-DMA staging pays once the K loop is long enough to amortise the lower occupancy (2 x 32 KB stages per WG):
     // measured cross-over between the 128- and 256-channel 3x3 layers (18 vs 36 stages)
     const bool dma = g_tune[0] == 2 || (g_tune[0] == 3 && p.Kg / BK >= 32);
-    if (fast && dma) return launch_igemm_f<MODE, BM, BN, WM, TR, true, true>(p, st);
+    if (fast && g_tune[0] == 4) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 3>(p, st);
+    if (fast && g_tune[0] == 5) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 2, 32>(p, st);
+    if (fast && dma) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 2>(p, st);
   }
-  if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true, false>(p, st);
-  return launch_igemm_f<MODE, BM, BN, WM, TR, false, false>(p, st);
+  if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 0>(p, st);
+  return launch_igemm_f<MODE, BM, BN, WM, TR, false, 0>(p, st);
 }
 
-template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, bool DMA>
+template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT>
 int launch_igemm_f(IgemmP& p, hipStream_t st) {
   p.tiles_n = cdiv((p.K + 7) / 8 * 8, BN);
   int tiles_m = cdiv(p.M, BM);
@@ -621,7 +659,7 @@ int launch_igemm_f(IgemmP& p, hipStream_t st) {
   p.fd_st = make_fd((unsigned)p.stride);
   int gy = 1;
   if (p.ws != nullptr) {
-    const int nk = p.Kg / BK;
+    const int nk = p.Kg / BKT;
     gy = p.ksplit;                 // requested number of slices
     if (gy > nk) gy = nk;
     p.ksplit = cdiv(nk, gy);       // K-stages per slice
@@ -629,8 +667,8 @@ int launch_igemm_f(IgemmP& p, hipStream_t st) {
   } else {
     p.ksplit = 0;
   }
-  constexpr size_t smem = igemm_smem<MODE, BM, BN, DMA>();
-  auto kern = igemm_kernel<MODE, BM, BN, WM, TR, FAST, DMA>;
+  constexpr size_t smem = igemm_smem<MODE, BM, BN, DMA, BKT>();
+  auto kern = igemm_kernel<MODE, BM, BN, WM, TR, FAST, DMA, BKT>;
   if (smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem);
