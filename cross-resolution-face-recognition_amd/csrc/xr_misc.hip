@@ -161,6 +161,56 @@ __global__ void upadd2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dlow
   }
 }
 
+__device__ __forceinline__ int reflect_idx(int i, int n) {  // index i in [-p, n+p) mirrored into [0, n), p < n
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+template <typename T>
+__global__ void reflect_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int p) {
+  const int Ho = H + 2 * p, Wo = W + 2 * p, cpr = C / 8;
+  GRID_STRIDE(i, (int64_t)N * Ho * Wo * cpr) {
+    const int ch = (int)(i % cpr);
+    int64_t pix = i / cpr;
+    const int wo = (int)(pix % Wo); pix /= Wo;
+    const int ho = (int)(pix % Ho);
+    const int n = (int)(pix / Ho);
+    float v[8];
+    ld8(x + (((size_t)n * H + reflect_idx(ho - p, H)) * W + reflect_idx(wo - p, W)) * C + ch * 8, v);
+    st8(y + (size_t)i * 8, v);
+  }
+}
+template <typename T>
+__global__ void reflect_pad_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int p) {
+  // one thread per INPUT pixel chunk: its own image at (h+p, w+p) plus the mirrored pre-images in each dimension
+  const int Ho = H + 2 * p, Wo = W + 2 * p, cpr = C / 8;
+  GRID_STRIDE(i, (int64_t)N * H * W * cpr) {
+    const int ch = (int)(i % cpr);
+    int64_t pix = i / cpr;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H);
+    const int n = (int)(pix / H);
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = h + p;
+    if (h >= 1 && h <= p) hs[nh++] = p - h;
+    if (h <= H - 2 && h >= H - 1 - p) hs[nh++] = 2 * (H - 1) - h + p;
+    ws[nw++] = w + p;
+    if (w >= 1 && w <= p) ws[nw++] = p - w;
+    if (w <= W - 2 && w >= W - 1 - p) ws[nw++] = 2 * (W - 1) - w + p;
+    float a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    for (int a_ = 0; a_ < nh; ++a_)
+      for (int b_ = 0; b_ < nw; ++b_) {
+        float v[8];
+        ld8(dy + (((size_t)n * Ho + hs[a_]) * Wo + ws[b_]) * C + ch * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += v[e];
+      }
+    st8(dx + (size_t)i * 8, a);
+  }
+}
+
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ src, int lds_, int so, T* __restrict__ dst, int ldd, int doff,
                                      int64_t M, int C) {
@@ -560,6 +610,24 @@ extern "C" int xr_upadd2_bwd(int dtype, const void* dy, void* dlow, int N, int H
   XR_DISPATCH(dtype, hipLaunchKernelGGL(upadd2_bwd_kernel<T>, dim3(grid_for((int64_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(NT), 0,
                                         st, (const T*)dy, (T*)dlow, N, H, W, C));
   XR_CHECK_LAUNCH("xr_upadd2_bwd");
+  return XR_OK;
+}
+extern "C" int xr_reflect_pad(int dtype, const void* x, void* y, int N, int H, int W, int C, int pad, void* stream) {
+  if (int e = chk_img("xr_reflect_pad", dtype, N, H, W, C)) return e;
+  XR_CHECK_ARG(x && y && pad >= 1 && pad < H && pad < W, "xr_reflect_pad: pad must be in [1, min(H,W))");
+  hipStream_t st = (hipStream_t)stream;
+  XR_DISPATCH(dtype, hipLaunchKernelGGL(reflect_pad_kernel<T>, dim3(grid_for((int64_t)N * (H + 2 * pad) * (W + 2 * pad) * (C / 8))),
+                                        dim3(NT), 0, st, (const T*)x, (T*)y, N, H, W, C, pad));
+  XR_CHECK_LAUNCH("xr_reflect_pad");
+  return XR_OK;
+}
+extern "C" int xr_reflect_pad_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int pad, void* stream) {
+  if (int e = chk_img("xr_reflect_pad_bwd", dtype, N, H, W, C)) return e;
+  XR_CHECK_ARG(dy && dx && pad >= 1 && pad < H && pad < W, "xr_reflect_pad_bwd: pad must be in [1, min(H,W))");
+  hipStream_t st = (hipStream_t)stream;
+  XR_DISPATCH(dtype, hipLaunchKernelGGL(reflect_pad_bwd_kernel<T>, dim3(grid_for((int64_t)N * H * W * (C / 8))), dim3(NT), 0, st,
+                                        (const T*)dy, (T*)dx, N, H, W, C, pad));
+  XR_CHECK_LAUNCH("xr_reflect_pad_bwd");
   return XR_OK;
 }
 extern "C" int xr_copy_channels(int dtype, const void* src, int lds_, int src_off, void* dst, int ldd, int dst_off, int64_t M,

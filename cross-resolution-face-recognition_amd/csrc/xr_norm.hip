@@ -36,11 +36,13 @@ static dim3 geo_grid(const Geo& g) { return dim3((unsigned)cdiv(g.rows, g.rows_p
 __device__ __forceinline__ float act_fwd(float z, float a, int act) {
   if (act == XR_ACT_PRELU) return z > 0.f ? z : a * z;
   if (act == XR_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == XR_ACT_TANH) return tanhf(z);
   return z;
 }
 __device__ __forceinline__ float act_grad(float z, float a, int act) {
   if (act == XR_ACT_PRELU) return z > 0.f ? 1.f : a;
   if (act == XR_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == XR_ACT_TANH) { const float th = tanhf(z); return 1.f - th * th; }
   return 1.f;
 }
 

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libxrface.so")
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "xrface.h"))
 
 XR_BF16, XR_F32 = 0, 1
-ACT_NONE, ACT_PRELU, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,

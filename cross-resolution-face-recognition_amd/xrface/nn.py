@@ -99,6 +99,24 @@ class ReLU(nn.ReLU):
         return leave(self.f(enter(x)))
 
 
+class Tanh(nn.Tanh):
+    def f(self, buf):
+        return ops.norm_act(buf, mode="none", act="tanh")
+
+    def forward(self, x):
+        return leave(self.f(enter(x)))
+
+
+class ReflectionPad2d(nn.ReflectionPad2d):
+    def f(self, buf):
+        p = self.padding
+        assert p[0] == p[1] == p[2] == p[3], "xrface.ReflectionPad2d: uniform padding only"
+        return ops.reflect_pad(buf, p[0])
+
+    def forward(self, x):
+        return leave(self.f(enter(x)))
+
+
 class Dropout(nn.Dropout):
     """Dropout(p) with a counter-based stream; ``inject_mask`` (uint8, NHWC layout of the input buffer) pins it
     for parity tests."""

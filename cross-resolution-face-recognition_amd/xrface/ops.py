@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 from torch.autograd import Function
 
-from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, XR_BF16, XR_F32, dt, lib, ptr, stream
+from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, lib, ptr, stream
 
 EPS = 1e-5
 import os as _os
@@ -461,7 +461,7 @@ def linear_nhwc(x, w, b=None):
 
 
 # ------------------------------------------------------------------------------------------------- norm + act
-_ACT = {None: ACT_NONE, "none": ACT_NONE, "prelu": ACT_PRELU, "relu": ACT_RELU}
+_ACT = {None: ACT_NONE, "none": ACT_NONE, "prelu": ACT_PRELU, "relu": ACT_RELU, "tanh": ACT_TANH}
 
 
 class _NormAct(Function):
@@ -870,6 +870,31 @@ class _AddSub(Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, (dy if ctx.sign > 0 else -dy), None
+
+
+class _ReflectPad(Function):
+    """nn.ReflectionPad2d(p) on an NHWC buffer (SUPER_RESOLUTION/model/FSRnet.py:255-292)."""
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = _c(x)
+        N, H, W, C = x.shape
+        y = torch.empty((N, H + 2 * p, W + 2 * p, C), dtype=x.dtype, device=x.device)
+        lib.xr_reflect_pad(dt(x), ptr(x), ptr(y), N, H, W, C, p, stream())
+        ctx.meta = (N, H, W, C, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C, p = ctx.meta
+        dy = _c(dy)
+        dx = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+        lib.xr_reflect_pad_bwd(dt(dy), ptr(dy), ptr(dx), N, H, W, C, p, stream())
+        return dx, None
+
+
+def reflect_pad(x, p):
+    return _ReflectPad.apply(x, int(p))
 
 
 def subsample(x, stride):

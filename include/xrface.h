@@ -41,6 +41,7 @@ extern "C" {
 #define XR_ACT_NONE 0
 #define XR_ACT_PRELU 1  /* per-channel slope */
 #define XR_ACT_RELU 2
+#define XR_ACT_TANH 3  /* SUPER_RESOLUTION/model/FSRnet.py:292 */
 
 const char* xr_last_error(void);
 int xr_version(void);
@@ -183,6 +184,10 @@ int xr_maxpool2_bwd(int dtype, const void* x, const void* dy, void* dx, int N, i
 /* out = up1 + nearest_up2(low) (model/FSRnet.py:210-211); bwd: dlow = 2x2 sum of dy (dup1 = dy). */
 int xr_upadd2(int dtype, const void* up1, const void* low, void* y, int N, int H, int W, int C, void* stream);
 int xr_upadd2_bwd(int dtype, const void* dy, void* dlow, int N, int H, int W, int C, void* stream);
+/* nn.ReflectionPad2d(p) (SUPER_RESOLUTION/model/FSRnet.py:255-292): y [N][H+2p][W+2p][C]; bwd folds the mirrored
+ * border gradients back (each input pixel gathers its <= 4 pre-images, no atomics). */
+int xr_reflect_pad(int dtype, const void* x, void* y, int N, int H, int W, int C, int pad, void* stream);
+int xr_reflect_pad_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, int pad, void* stream);
 /* channel-slice copy: dst[m][dst_off + c] = src[m][src_off + c], c < C  (torch.cat, model/FSRnet.py:505,534) */
 int xr_copy_channels(int dtype, const void* src, int lds_, int src_off, void* dst, int ldd, int dst_off, int64_t M,
                      int C, void* stream);

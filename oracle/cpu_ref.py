@@ -149,6 +149,91 @@ def fhn_forward(sds, lr_img):
     return sr, coarse_img, lmk, par
 
 
+# ----------------------------------------------------------------------------- FSRNet (SR variant)
+# SUPER_RESOLUTION/model/FSRnet.py:12-35,77-156,251-416 restated as a small interpreter over layer specs; the spec
+# positions ARE the reference's nn.Sequential indices, so state_dict keys line up ("model.<i>.weight").
+
+def _rconv(sd, key, x, pad, stride=1):
+    if pad:
+        x = F.pad(x, (pad,) * 4, mode="reflect")
+    return F.conv2d(x, sd[key + ".weight"], sd.get(key + ".bias"), stride)
+
+
+def _sr_resblock(sd, p, x):
+    y = F.prelu(_inorm(sd, p + ".in1", _conv(sd, p + ".conv1", x, 1, 1)), sd[p + ".relu.weight"])
+    return _inorm(sd, p + ".in2", _conv(sd, p + ".conv2", y, 1, 1)) + x
+
+
+def _sr_bottleneck(sd, p, x):
+    y = _conv(sd, p + ".conv1", F.relu(F.instance_norm(x, eps=EPS)))
+    y = _conv(sd, p + ".conv2", F.relu(F.instance_norm(y, eps=EPS)), 1, 1)
+    y = _conv(sd, p + ".conv3", F.relu(F.instance_norm(y, eps=EPS)))
+    return y + x
+
+
+def _sr_hourglass(sd, p, x, n, nblocks=3):
+    def seq(q, t):
+        for j in range(nblocks):
+            t = _sr_bottleneck(sd, f"{q}.{j}", t)
+        return t
+    up1 = seq(f"{p}.{n - 1}.0", x)
+    low = seq(f"{p}.{n - 1}.1", F.max_pool2d(x, 2, stride=2))
+    low = _sr_hourglass(sd, p, low, n - 1, nblocks) if n > 1 else seq(f"{p}.{n - 1}.3", low)
+    low = seq(f"{p}.{n - 1}.2", low)
+    return up1 + F.interpolate(low, scale_factor=2)
+
+
+def _sr_generator(sd, x, head, n_blocks=6, tail_out=False):
+    """head: list of (seq index, reflect pad, stride, followed by IN+ReLU); then n_blocks residual blocks, then the
+    shared up-sampling tail {convT, pad+conv, IN, ReLU} x 2; optional `out` = pad + conv + tanh."""
+    i = 0
+    for idx, pad, stride, norm in head:
+        x = _rconv(sd, f"model.{idx}", x, pad, stride)
+        if norm:
+            x = F.relu(F.instance_norm(x, eps=EPS))
+        i = idx
+    i = i + 3 if head[-1][3] else i + 1          # skip IN, ReLU positions
+    for _ in range(n_blocks):
+        x = _sr_resblock(sd, f"model.{i}", x)
+        i += 1
+    for _ in range(2):
+        x = F.conv_transpose2d(x, sd[f"model.{i}.weight"], None, stride=2, padding=1, output_padding=1)
+        x = F.relu(F.instance_norm(_rconv(sd, f"model.{i + 2}", x, 1), eps=EPS))
+        i += 5
+    if tail_out:
+        x = torch.tanh(_rconv(sd, "out.1", x, 1))
+    return x
+
+
+def sr_coarse(sd, x):
+    """Coarse_SR_Network (SUPER_RESOLUTION/model/FSRnet.py:251-298)."""
+    return _sr_generator(sd, x, [(1, 3, 1, True), (5, 1, 2, False), (7, 1, 1, True), (11, 1, 2, False), (13, 1, 1, True)],
+                         tail_out=True)
+
+
+def sr_encoder(sd, x):
+    """Fine_SR_Encoder (:301-342)."""
+    return _sr_generator(sd, x, [(1, 1, 1, False), (3, 1, 2, False), (5, 1, 1, True), (9, 1, 2, False), (11, 1, 1, True)])
+
+
+def sr_decoder(sd, x):
+    """Fine_SR_Decoder (:373-416)."""
+    return _sr_generator(sd, x, [(1, 1, 2, False), (3, 1, 1, True), (7, 1, 2, False), (9, 1, 1, True)], tail_out=True)
+
+
+def sr_prior(sd, x, n_hourglass=4, n_blocks=2):
+    """Prior_Estimation_Network (:345-370) -> (feat, landmark, parsing)."""
+    y = F.relu(F.instance_norm(_rconv(sd, "model.1", x, 3), eps=EPS))
+    i = 4
+    for _ in range(n_blocks):
+        y = _sr_resblock(sd, f"model.{i}", y)
+        i += 1
+    for _ in range(n_hourglass):
+        y = _sr_hourglass(sd, f"model.{i}.hg", y, 4)
+        i += 1
+    return y, _conv(sd, "fc_landmark", y), _conv(sd, "fc", y)
+
+
 # ----------------------------------------------------------------------------- IR / IR-SE backbone
 
 IR50_UNITS = ((64, 64, 3), (64, 128, 4), (128, 256, 14), (256, 512, 3))  # model_irse.py:104-110

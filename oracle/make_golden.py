@@ -162,6 +162,38 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fsrnet_root.npz"), **st)
     print(f"[golden] fsrnet_root ok ({time.time() - t0:.1f}s)")
 
+    # ------------------------------------------------------------------ FSRNet SR variant (a8, a9)
+    fsr_sr = ref_import("SUPER_RESOLUTION.model.FSRnet")
+    st = {}
+    hr1 = G.synth_faces(1, 112, seed=1, start=400)
+    lr1 = G.synth_lr_from_hr(hr1)
+    sr_nets = dict(coarse=fsr_sr.Coarse_SR_Network(), encoder=fsr_sr.Fine_SR_Encoder(),
+                   prior=fsr_sr.Prior_Estimation_Network(), decoder=fsr_sr.Fine_SR_Decoder())
+    sr_sds = {}
+    for name, m in sr_nets.items():
+        sr_sds[name] = load_det(m, 3)
+        keys["fsrnet_sr." + name] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    c_img = sr_nets["coarse"](lr1)
+    close(R.sr_coarse(sr_sds["coarse"], lr1), c_img, "sr coarse"); pack(st, "coarse/img", c_img)
+    e_ft = sr_nets["encoder"](c_img)
+    close(R.sr_encoder(sr_sds["encoder"], c_img), e_ft, "sr encoder"); pack(st, "encoder/out", e_ft)
+    p_ft, p_lm, p_pa = sr_nets["prior"](c_img)
+    m_ft, m_lm, m_pa = R.sr_prior(sr_sds["prior"], c_img)
+    close(m_ft, p_ft, "sr prior feat", 5e-4); close(m_lm, p_lm, "sr prior lmk", 5e-4); close(m_pa, p_pa, "sr prior parsing", 5e-4)
+    pack(st, "prior/feat", p_ft); pack(st, "prior/landmark", p_lm); pack(st, "prior/parsing", p_pa)
+    d_img = sr_nets["decoder"](torch.cat((p_ft, e_ft), 1))
+    close(R.sr_decoder(sr_sds["decoder"], torch.cat((p_ft, e_ft), 1)), d_img, "sr decoder", 5e-4); pack(st, "decoder/img", d_img)
+    # one gradient check through the coarse generator: L = mse97(coarse, hr)
+    l_sr = loss_mod.MSELossFunc()(c_img, hr1)
+    g_ref = grads_ref(l_sr, sr_nets["coarse"], retain=True)
+    sdg = R.with_grad(sr_sds["coarse"])
+    g_mine = R.grads_of(R.mse97(R.sr_coarse(sdg, lr1), hr1), sdg)
+    compare_grads(g_ref, g_mine, "sr coarse", st, "coarse/", keep=("model.1.weight", "model.13.weight", "model.18.relu.weight",
+                                                                   "model.22.weight", "model.29.weight", "out.1.weight"))
+    st["coarse/loss"] = np.float64(l_sr.item())
+    np.savez_compressed(os.path.join(OUT, "fsrnet_sr.npz"), **st)
+    print(f"[golden] fsrnet_sr ok ({time.time() - t0:.1f}s)")
+
     # ------------------------------------------------------------------ IR-50 / IR-SE-50 (a10, a11, a13, a19)
     irse = ref_import("SUPER_RESOLUTION.model.model_irse")
     gdc = ref_import("SUPER_RESOLUTION.model.GroupDepthConv")

@@ -39,6 +39,10 @@ def test_argument_validation_without_gpu():
     ("ir50", "xrface.model.model_irse:IR_50"),
     ("irse50", "xrface.model.model_irse:IR_SE_50"),
     ("resnet34", "xrface.model.resnet:ResNet_34"),
+    ("fsrnet_sr.coarse", "xrface.model.FSRnet_sr:Coarse_SR_Network"),
+    ("fsrnet_sr.encoder", "xrface.model.FSRnet_sr:Fine_SR_Encoder"),
+    ("fsrnet_sr.prior", "xrface.model.FSRnet_sr:Prior_Estimation_Network"),
+    ("fsrnet_sr.decoder", "xrface.model.FSRnet_sr:Fine_SR_Decoder"),
 ])
 def test_state_dict_surface_matches_reference(name, ctor):
     import importlib

@@ -220,3 +220,66 @@ def test_bf16_throughput_mode_embedding_error_is_reported():
     err = float((emb.cpu() - ref).norm(dim=1).max() / ref.norm(dim=1).min())
     print(f"[bf16] IR-SE-50 embedding relative L2 error vs fp32 reference: {err:.3e}")
     assert err < 0.1
+
+
+def test_c5_full_size_properties():
+    """BASELINE config 5 at its full size (P = 1e6 pairs, 4000 thresholds, 10 folds): size-independent properties --
+    the histogram accounts for every pair exactly once, TPR/FPR are monotone in the threshold, the end points are
+    0 and 1, and a 20 000-pair sample of the distances matches numpy."""
+    from xrface.utils.utils import calculate_roc, pair_dist, roc_histograms
+    P = 1_000_000
+    g = torch.Generator(device=DEV); g.manual_seed(0)
+    e1 = torch.randn(P, 512, device=DEV, generator=g)
+    same = torch.rand(P, device=DEV, generator=g) < 0.5
+    e2 = torch.where(same[:, None], e1 + 0.5 * torch.randn(P, 512, device=DEV, generator=g),
+                     torch.randn(P, 512, device=DEV, generator=g))
+    dist = pair_dist(e1, e2)
+    idx = torch.arange(0, P, 50, device=DEV)
+    ref = np.sum(np.square(e1[idx].cpu().numpy() - e2[idx].cpu().numpy()), 1)
+    assert np.abs(dist[idx].cpu().numpy() - ref).max() / ref.max() < 2e-6
+    thresholds = np.arange(0, 12000, 3)
+    fold = np.random.RandomState(0).randint(0, 10, P).astype(np.int32)
+    hist = roc_histograms(dist, same.cpu().numpy(), fold, thresholds, 10).cpu().numpy()
+    assert hist.sum() == P and (hist >= 0).all()
+    assert hist[:, 1].sum() == int(same.sum()) and np.array_equal(hist.sum(axis=(1, 2)), np.bincount(fold, minlength=10))
+    tpr, fpr, acc, best = calculate_roc(thresholds, e1, e2, same.cpu().numpy(), nrof_folds=10, fold_id=fold)
+    assert (np.diff(tpr) >= 0).all() and (np.diff(fpr) >= 0).all()
+    assert tpr[0] == 0.0 and fpr[0] == 0.0 and tpr[-1] == 1.0 and fpr[-1] == 1.0
+    assert 0.99 < acc <= 1.0 and len(best) == 10
+
+
+def test_fsrnet_sr_variant_forward_and_coarse_grads():
+    """SR-variant generators (SUPER_RESOLUTION/model/FSRnet.py): ReflectionPad + conv, k3/s2 deconv, Tanh, 4 x depth-4
+    bottleneck hourglass.  Forward outputs vs the reference fixture, and gradients of mse97(coarse, hr)."""
+    import xrface
+    from xrface.loss.loss import MSELossFunc
+    from xrface.model import FSRnet_sr as M
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("fsrnet_sr.npz")
+    hr = G.synth_faces(1, 112, seed=1, start=400)
+    lr = G.synth_lr_from_hr(hr)
+    coarse, _ = load_det(M.Coarse_SR_Network(), 3)
+    enc, _ = load_det(M.Fine_SR_Encoder(), 3)
+    prior, _ = load_det(M.Prior_Estimation_Network(), 3)
+    dec, _ = load_det(M.Fine_SR_Decoder(), 3)
+    c = coarse(lr.to(DEV))
+    assert c.shape == (1, 3, 112, 112)
+    check_against(st, "coarse/img", c, TOL)
+    e = enc(c.detach())
+    check_against(st, "encoder/out", e, TOL)
+    pf, lm, pa = prior(c.detach())
+    assert lm.shape == (1, 68, 112, 112) and pa.shape == (1, 13, 112, 112)
+    check_against(st, "prior/feat", pf, TOL)
+    check_against(st, "prior/landmark", lm, TOL)
+    check_against(st, "prior/parsing", pa, TOL)
+    d = dec(torch.cat((pf, e), 1))
+    check_against(st, "decoder/img", d, TOL)
+    loss = MSELossFunc()(c, hr.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(st["coarse/loss"])) <= TOL * abs(float(st["coarse/loss"]))
+    g = grads_by_name(coarse)
+    pre = "coarse/grad/"
+    for key in st.files:
+        if key.startswith(pre):
+            name = key[len(pre):].replace("@digest", "")
+            check_against(st, pre + name, g[name], GRAD_TOL, floor=grad_floor(st, pre))
