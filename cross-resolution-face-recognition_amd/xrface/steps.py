@@ -52,6 +52,51 @@ def fhn_step(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
     return {k: v.detach() for k, v in losses.items()}, outs
 
 
+def fhn_perceptual_step(nets, backbone, lr_img, hr_img, heatmap, parsing, layer_list=("21", "22"), optimizers=None,
+                        lam_feature=1.0, lam_landmark=1.0, lam_parsing=1.0):
+    """SUPER_RESOLUTION/train_FHN.py:251-308: perceptual (IR-50 feature) losses.  ``nets`` = SR-variant generators
+    dict(coarse, prior, encoder, decoder); ``backbone`` = frozen IR-50 in eval mode (NOT under no_grad: the input
+    gradient flows through it back to the generator, :258-259).  Features are tapped with FeatureExtractor exactly as
+    the reference does.  ``optimizers`` (optional): dict(coarse, prior, encdec)."""
+    from .model.GroupDepthConv import FeatureExtractor
+    fe, mse, ce2d = FeatureExtractor(), MSELoss(), CrossEntropyLoss2d()
+    backbone.eval()
+
+    def feats(img):
+        d, _, _, _ = fe(backbone.input_layer(img), list(layer_list), backbone.body)
+        return [d[k] for k in layer_list]
+
+    coarse = nets["coarse"](lr_img)
+    with torch.no_grad():
+        f_hr = feats(hr_img)
+    f_c = feats(coarse)
+    l_coarse = lam_feature * sum(mse(a, b) for a, b in zip(f_hr, f_c))
+    pf, lmk, par = nets["prior"](coarse)
+    ef = nets["encoder"](coarse)
+    sr = nets["decoder"](torch.cat((pf, ef), 1))
+    # upstream Landmark_Loss raises (torch.pow without exponent); its evident intent mean((sum_c in - t)^2) is used
+    l_prior = lam_landmark * _LMK1(lmk, heatmap) + lam_parsing * ce2d(par, parsing)
+    f_sr = feats(sr)
+    l_ed = lam_feature * sum(mse(a, b) for a, b in zip(f_hr, f_sr))
+    _pair_grads(l_coarse, nets["coarse"], retain=True)
+    _pair_grads(l_prior, nets["prior"], retain=True)
+    params = [p for k in ("encoder", "decoder") for p in nets[k].parameters() if p.requires_grad]
+    _assign_grads(params, torch.autograd.grad(l_ed, params, allow_unused=True))
+    if optimizers is not None:
+        for k in ("coarse", "prior", "encdec"):
+            optimizers[k].step()
+    losses = dict(coarse=l_coarse.detach(), prior=l_prior.detach(), encdec=l_ed.detach())
+    return losses, dict(coarse=coarse.detach(), sr=sr.detach())
+
+
+class _Landmark1(torch.nn.Module):
+    def forward(self, input, target):
+        return ops.landmark_loss(input, target, 1.0)
+
+
+_LMK1 = _Landmark1()
+
+
 def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_optimizer=None, taps=(2, 6, 20, 23)):
     """Residual knowledge distillation: student matches the frozen teacher's embedding; the assistant learns the
     residual (teacher - student) at the four stage taps and the embedding."""

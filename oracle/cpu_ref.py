@@ -490,3 +490,30 @@ def fhn_step_grads(sds, lr_img, hr_img, heatmap, parsing):
     grads = {k: grads_of(losses[k], sds[k], retain=True) for k in ("coarse", "encoder", "prior", "decoder")}
     outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach())
     return {k: v.detach() for k, v in losses.items()}, outs, grads
+
+
+def fhn_perceptual_grads(sds, bb_sd, lr_img, hr_img, heatmap, parsing, taps=(21, 22), lam_feature=1.0, lam_landmark=1.0,
+                         lam_parsing=1.0):
+    """SUPER_RESOLUTION/train_FHN.py:251-308 at pre-step weights (SR-variant generators, frozen eval-mode IR-50 as the
+    perceptual backbone, features tapped after body blocks 21 and 22 = layer_list[-3:-1]):
+      L_coarse = lam_F * sum_l MSE(feat_l(hr), feat_l(coarse))            -> coarse
+      L_prior  = lam_L * landmark(lmk, heatmap) + lam_P * CE(parsing)      -> prior
+      L_encdec = lam_F * sum_l MSE(feat_l(hr), feat_l(sr))                 -> encoder + decoder
+    The upstream SR Landmark_Loss raises (torch.pow without exponent, SUPER_RESOLUTION/loss/loss.py:16); its evident
+    intent mean((sum_c in - target)^2) is used."""
+    sds = {k: with_grad(v) for k, v in sds.items()}
+    coarse = sr_coarse(sds["coarse"], lr_img)
+    with torch.no_grad():
+        _, f_hr = ir_backbone(bb_sd, hr_img, train=False, taps=taps)
+    _, f_c = ir_backbone(bb_sd, coarse, train=False, taps=taps)
+    l_coarse = lam_feature * sum(F.mse_loss(a, b) for a, b in zip(f_hr, f_c))
+    pf, lmk, par = sr_prior(sds["prior"], coarse)
+    ef = sr_encoder(sds["encoder"], coarse)
+    sr = sr_decoder(sds["decoder"], torch.cat((pf, ef), 1))
+    l_prior = lam_landmark * ((lmk.sum(1) - heatmap) ** 2).mean() + lam_parsing * nll2d(par, parsing)
+    _, f_sr = ir_backbone(bb_sd, sr, train=False, taps=taps)
+    l_ed = lam_feature * sum(F.mse_loss(a, b) for a, b in zip(f_hr, f_sr))
+    grads = {"coarse": grads_of(l_coarse, sds["coarse"], retain=True), "prior": grads_of(l_prior, sds["prior"], retain=True),
+             "encoder": grads_of(l_ed, sds["encoder"], retain=True), "decoder": grads_of(l_ed, sds["decoder"], retain=True)}
+    losses = dict(coarse=l_coarse.detach(), prior=l_prior.detach(), encdec=l_ed.detach())
+    return losses, dict(coarse=coarse.detach(), sr=sr.detach()), grads
