@@ -455,6 +455,53 @@ __global__ __launch_bounds__(NT) void l2norm_rows_bwd_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------------------------------------ MMD (build-defined)
+// biased multi-bandwidth Gaussian-kernel MMD^2 between a = z[0:N] and b = z[N:2N] (D floats per row):
+//   L = mean K(a,a) + mean K(b,b) - 2 mean K(a,b),  K(x,y) = sum_s exp(-|x-y|^2 / (2 sigma_s^2)).
+// One wave per (i, j) pair: d2 by a wave reduction; w[i][j] = dL/d(d2_ij) is kept for the backward pass.
+__global__ __launch_bounds__(NT) void mmd_fwd_kernel(const float* __restrict__ z, float* __restrict__ w, float* __restrict__ loss,
+                                                     int N, int D, const float* __restrict__ sig, int ns) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pair = (blockIdx.x * (int64_t)NT + threadIdx.x) >> 6;
+  const int M = 2 * N;
+  float contrib = 0.f;
+  if (pair < (int64_t)M * M) {
+    const int i = (int)(pair / M), j = (int)(pair - (int64_t)i * M);
+    float d2 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float t = z[(size_t)i * D + d] - z[(size_t)j * D + d];
+      d2 += t * t;
+    }
+    d2 = wave_sum(d2);
+    if (lane == 0) {
+      const float sgn = ((i < N) == (j < N)) ? 1.f : -1.f;
+      const float coef = sgn / ((float)N * (float)N);
+      float k = 0.f, dk = 0.f;
+      for (int s = 0; s < ns; ++s) {
+        const float g = 1.f / (2.f * sig[s] * sig[s]);
+        const float e = __expf(-d2 * g);
+        k += e;
+        dk -= g * e;
+      }
+      w[pair] = coef * dk;
+      contrib = coef * k;
+    }
+  }
+  block_atomic_sum(contrib, loss);
+}
+// dz[i] = gscale * 2 * sum_j (w[i][j] + w[j][i]) * (z[i] - z[j]); one block per row i
+__global__ __launch_bounds__(NT) void mmd_bwd_kernel(const float* __restrict__ z, const float* __restrict__ w, float* __restrict__ dz,
+                                                     int M, int D, const float* __restrict__ gdev) {
+  const int i = blockIdx.x;
+  const float gs = gdev ? *gdev : 1.f;
+  for (int d = threadIdx.x; d < D; d += NT) {
+    const float zi = z[(size_t)i * D + d];
+    float a = 0.f;
+    for (int j = 0; j < M; ++j) a += (w[(size_t)i * M + j] + w[(size_t)j * M + i]) * (zi - z[(size_t)j * D + d]);
+    dz[(size_t)i * D + d] = 2.f * gs * a;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ optimizers
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, int64_t n, float lr,
                            float momentum, float wd, const uint8_t* __restrict__ wd_mask, int first) {
@@ -762,6 +809,21 @@ extern "C" int xr_l2norm_rows_bwd(const float* y, const float* inv_norm, const f
   hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3(grid_for(M, 4, 4096)), dim3(NT), 0, (hipStream_t)stream, y, inv_norm, dy, dx, M,
                      C);
   XR_CHECK_LAUNCH("xr_l2norm_rows_bwd");
+  return XR_OK;
+}
+
+extern "C" int xr_mmd_fwd(const float* z, float* w, float* loss, int N, int D, const float* sigmas, int nsig, void* stream) {
+  XR_CHECK_ARG(z && w && loss && sigmas && N > 0 && D > 0 && nsig > 0, "xr_mmd_fwd: bad arguments");
+  const int64_t pairs = (int64_t)4 * N * N;
+  hipLaunchKernelGGL(mmd_fwd_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(NT), 0, (hipStream_t)stream, z, w, loss, N, D, sigmas,
+                     nsig);
+  XR_CHECK_LAUNCH("xr_mmd_fwd");
+  return XR_OK;
+}
+extern "C" int xr_mmd_bwd(const float* z, const float* w, float* dz, int N, int D, const float* gscale_dev, void* stream) {
+  XR_CHECK_ARG(z && w && dz && N > 0 && D > 0, "xr_mmd_bwd: bad arguments");
+  hipLaunchKernelGGL(mmd_bwd_kernel, dim3(2 * N), dim3(NT), 0, (hipStream_t)stream, z, w, dz, 2 * N, D, gscale_dev);
+  XR_CHECK_LAUNCH("xr_mmd_bwd");
   return XR_OK;
 }
 

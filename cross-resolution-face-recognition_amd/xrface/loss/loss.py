@@ -56,3 +56,9 @@ class ArcFaceHead(nn.Module):
 
     def forward(self, emb, target):
         return ops.arcface_logits(emb, self.weight, target, self.s, self.m)
+
+
+def MMD(source, target, sigmas=(1.0, 2.0, 4.0, 8.0, 16.0)):
+    """``from loss.loss import MMD`` (Face_Hallucination_sub_Net.py:25) -- undefined upstream; build-defined as the biased
+    multi-bandwidth Gaussian-kernel MMD^2 (fp64 restatement: oracle/cpu_ref.py:mmd_gaussian)."""
+    return ops.mmd(source, target, sigmas)

@@ -1136,3 +1136,35 @@ def arcface_logits(emb, weight, target, s=64.0, m=0.5):
     n, d = e.shape
     cos = leave2d(linear_nhwc(e.reshape(n, 1, 1, d), w, None))[:, :w.shape[0]]
     return _ArcMargin.apply(cos, target, float(s), float(m))
+
+
+# ------------------------------------------------------------------------------------------------- MMD
+class _MMD(Function):
+    """Biased multi-bandwidth Gaussian-kernel MMD^2 between two (N, D) batches (build-defined)."""
+
+    @staticmethod
+    def forward(ctx, a, b, sigmas):
+        _need_cuda(a)
+        assert a.shape == b.shape and a.dim() == 2
+        z = torch.cat((a.detach().float(), b.detach().float()), 0).contiguous()
+        n, d = a.shape
+        sg = torch.tensor(list(sigmas), dtype=torch.float32, device=a.device)
+        w = torch.empty((2 * n, 2 * n), dtype=torch.float32, device=a.device)
+        loss = zeros_f32((1,), a.device).view(())
+        lib.xr_mmd_fwd(ptr(z), ptr(w), ptr(loss), n, d, ptr(sg), sg.numel(), stream())
+        ctx.save_for_backward(z, w)
+        ctx.meta = (n, d, a.dtype, b.dtype)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        z, w = ctx.saved_tensors
+        n, d, adt, bdt = ctx.meta
+        g = _c(g.float())
+        dz = torch.empty_like(z)
+        lib.xr_mmd_bwd(ptr(z), ptr(w), ptr(dz), n, d, ptr(g), stream())
+        return dz[:n].to(adt), dz[n:].to(bdt), None
+
+
+def mmd(a, b, sigmas=(1.0, 2.0, 4.0, 8.0, 16.0)):
+    return _MMD.apply(a, b, tuple(float(s) for s in sigmas))

@@ -227,6 +227,11 @@ int xr_loss_softmax_ce(int dtype, const void* pred, const int64_t* target, float
  * logits = s*(phi(cos) at target else cos); dlogit scaling handled by xr_arcface_bwd. */
 int xr_arcface_margin(float* cos_logits, const int64_t* target, float* dphi_dcos, int64_t M, int C, float s,
                       float m, void* stream);
+/* Build-defined MMD (the reference imports an undefined `MMD`, Face_Hallucination_sub_Net.py:25): biased
+ * multi-bandwidth Gaussian-kernel MMD^2 between z[0:N] and z[N:2N] (fp32 [2N][D]).  fwd accumulates the value into
+ * loss[0] and stores w [2N][2N] = dL/d|z_i - z_j|^2; bwd: dz = gscale * 2 * sum_j (w_ij + w_ji)(z_i - z_j). */
+int xr_mmd_fwd(const float* z, float* w, float* loss, int N, int D, const float* sigmas, int nsig, void* stream);
+int xr_mmd_bwd(const float* z, const float* w, float* dz, int N, int D, const float* gscale_dev, void* stream);
 /* row-wise L2 normalisation y = x/||x|| and its backward (l2_norm, model_irse.py:16-20). */
 int xr_l2norm_rows(const float* x, float* y, float* inv_norm, int64_t M, int C, void* stream);
 int xr_l2norm_rows_bwd(const float* y, const float* inv_norm, const float* dy, float* dx, int64_t M, int C,

@@ -378,3 +378,19 @@ def test_arcface_head_against_fp64_restatement():
     assert abs(loss.item() - l_ref.item()) < 1e-3 * abs(l_ref.item())
     assert rel(eg.grad, e64.grad) < 2e-3
     assert rel(head.weight.grad, w64.grad) < 2e-3
+
+
+def test_mmd_against_fp64_restatement():
+    """MMD is imported-but-undefined upstream (parity unpinned): checked against the oracle's fp64 restatement."""
+    from oracle import cpu_ref as R
+    from xrface.loss.loss import MMD
+    n, d = 24, 512
+    a, b = rnd("mma", n, d) * 0.3, rnd("mmb", n, d) * 0.3 + 0.05
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = R.mmd_gaussian(a64, b64)
+    ref.backward()
+    ag, bg = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    val = MMD(ag, bg)
+    (val * 2.0).backward()
+    assert abs(val.item() - ref.item()) < 1e-4 * abs(ref.item()) + 1e-7
+    assert rel(ag.grad, a64.grad * 2.0) < 1e-3 and rel(bg.grad, b64.grad * 2.0) < 1e-3
