@@ -1047,6 +1047,161 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __r
   }
 }
 
+// B % 4 == 0: one thread sums four consecutive packed columns over its slice group with 16-B loads (four slices in
+// flight).  blockIdx.y selects a group of `spg` slices; with more than one group the groups meet in dst by atomicAdd
+// (dst then holds the running gradient or was zeroed by the launcher).
+__global__ void unpack_wgrad4_kernel(const float* __restrict__ packed, float* __restrict__ dst, int A2, int taps, int B4,
+                                     int Bp, int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate,
+                                     int nslices, int64_t slice_stride, int64_t total4, int spg) {
+  const int s_beg = blockIdx.y * spg;
+  const int s_end = (s_beg + spg < nslices) ? s_beg + spg : nslices;
+  const bool atomic = gridDim.y > 1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i % B4) * 4;
+    const int64_t r = i / B4;
+    const int tp = (int)(r % taps);
+    const int64_t a = r / taps;
+    const int64_t a1 = a / A2, a2 = a - a1 * A2;
+    const float* src = packed + a * Kg + (int64_t)tp * Bp + b;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sl = s_beg;
+    for (; sl + 3 < s_end; sl += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(src + (sl + q) * slice_stride);
+        v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;
+      }
+    }
+    for (; sl < s_end; ++sl) {
+      const float4 x = *reinterpret_cast<const float4*>(src + sl * slice_stride);
+      v[0].x += x.x; v[0].y += x.y; v[0].z += x.z; v[0].w += x.w;
+    }
+    const float o[4] = {(v[0].x + v[1].x) + (v[2].x + v[3].x), (v[0].y + v[1].y) + (v[2].y + v[3].y),
+                        (v[0].z + v[1].z) + (v[2].z + v[3].z), (v[0].w + v[1].w) + (v[2].w + v[3].w)};
+    float* d = dst + a1 * sa1 + a2 * sa2 + tp * st_ + (int64_t)b * sb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (atomic) atomicAdd(d + e * sb, o[e]);
+      else d[e * sb] = (accumulate & 1) ? (d[e * sb] + o[e]) : o[e];
+    }
+  }
+}
+
+// ---- LDS-tiled layout converters for the two conv-shaped cases (both sides of the transpose stay coalesced) ----------
+// (1) parameter [A][B][taps] (taps contiguous: Conv2d [K][C][R][S], Linear [K][C*HW])  <->  pack [A][tap][Bp]
+//     block = (row a, 64 consecutive b): 64*taps contiguous floats on the parameter side, 64-wide rows on the pack side
+__global__ __launch_bounds__(256) void pack_fwdform_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
+                                                           int taps, int B, int Bp, int Kg, int64_t plane) {
+  extern __shared__ float tile[];
+  const int a = blockIdx.y, b0 = blockIdx.x * 64, t = threadIdx.x;
+  const int nb = (B - b0) < 64 ? (B - b0) : 64;
+  const float* sp = src + ((int64_t)a * B + b0) * taps;
+  for (int j = t; j < nb * taps; j += 256) tile[j] = sp[j];
+  __syncthreads();
+  const int nbp = (Bp - b0) < 64 ? (Bp - b0) : 64;  // includes the zero padding columns b in [B, Bp)
+  for (int e = t; e < 64 * taps; e += 256) {
+    const int tp = e >> 6, bl = e & 63;
+    if (bl >= nbp) continue;
+    float v = bl < nb ? tile[bl * taps + tp] : 0.f;
+    bf16_t* dp = dst + (int64_t)a * Kg + (int64_t)tp * Bp + b0 + bl;
+    for (int q = 0; q < nplanes; ++q) {
+      const bf16_t h = f2bf(v);
+      dp[(int64_t)q * plane] = h;
+      v -= bf2f(h);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int j = taps * Bp + t; j < Kg; j += 256)
+      for (int q = 0; q < nplanes; ++q) dst[(int64_t)q * plane + (int64_t)a * Kg + j] = 0;
+}
+
+__global__ __launch_bounds__(256) void unpack_fwdform_kernel(const float* __restrict__ packed, float* __restrict__ dst, int taps,
+                                                             int B, int Bp, int Kg, int accumulate, int nslices,
+                                                             int64_t slice_stride) {
+  extern __shared__ float tile[];
+  const int a = blockIdx.y, b0 = blockIdx.x * 64, t = threadIdx.x;
+  const int nb = (B - b0) < 64 ? (B - b0) : 64;
+  for (int e = t; e < 64 * taps; e += 256) {
+    const int tp = e >> 6, bl = e & 63;
+    if (bl >= nb) continue;
+    const float* sp = packed + (int64_t)a * Kg + (int64_t)tp * Bp + b0 + bl;
+    float v = 0.f;
+    for (int sl = 0; sl < nslices; ++sl) v += sp[sl * slice_stride];
+    tile[bl * taps + tp] = v;
+  }
+  __syncthreads();
+  float* dp = dst + ((int64_t)a * B + b0) * taps;
+  for (int j = t; j < nb * taps; j += 256) dp[j] = accumulate ? dp[j] + tile[j] : tile[j];
+}
+
+// (2) parameter [B][A][taps] -> pack [A][tap][Bp]  (the input-gradient pack of a Conv2d: rows = input channel a,
+//     columns = (tap, output channel b)): block = (4 rows a, 64 columns b)
+__global__ __launch_bounds__(256) void pack_dgradform_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
+                                                             int taps, int A, int B, int Bp, int Kg, int64_t plane) {
+  extern __shared__ float tile[];  // [64][4*taps + 1]
+  const int a0 = blockIdx.y * 4, b0 = blockIdx.x * 64, t = threadIdx.x;
+  const int na = (A - a0) < 4 ? (A - a0) : 4, nb = (B - b0) < 64 ? (B - b0) : 64;
+  const int rowlen = na * taps, pitch = 4 * taps + 1;
+  for (int e = t; e < 64 * rowlen; e += 256) {
+    const int bl = e / rowlen, r = e - bl * rowlen;
+    if (bl < nb) tile[bl * pitch + r] = src[((int64_t)(b0 + bl) * A + a0) * taps + r];
+  }
+  __syncthreads();
+  const int nbp = (Bp - b0) < 64 ? (Bp - b0) : 64;
+  for (int e = t; e < na * taps * 64; e += 256) {
+    const int bl = e & 63, rt = e >> 6;      // rt = al * taps + tp
+    if (bl >= nbp) continue;
+    const int al = rt / taps, tp = rt - al * taps;
+    float v = bl < nb ? tile[bl * pitch + rt] : 0.f;
+    bf16_t* dp = dst + (int64_t)(a0 + al) * Kg + (int64_t)tp * Bp + b0 + bl;
+    for (int q = 0; q < nplanes; ++q) {
+      const bf16_t h = f2bf(v);
+      dp[(int64_t)q * plane] = h;
+      v -= bf2f(h);
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int al = 0; al < na; ++al)
+      for (int j = taps * Bp + t; j < Kg; j += 256)
+        for (int q = 0; q < nplanes; ++q) dst[(int64_t)q * plane + (int64_t)(a0 + al) * Kg + j] = 0;
+}
+
+// (3) Linear input-gradient pack: dst[(p*C + c)][k] = W[k][c*HW + p]  (rows in NHWC-flatten order, k contiguous).
+//     block = (64 k, 8 c): each k contributes 8*HW contiguous source floats; each (p, c) row gets 64 contiguous k
+__global__ __launch_bounds__(256) void pack_lindgrad_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
+                                                            int HW, int C, int K, int Bp, int Kg, int64_t plane) {
+  extern __shared__ float tile[];  // [64][8*HW + 1]
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 8, t = threadIdx.x;
+  const int nk = (K - k0) < 64 ? (K - k0) : 64, nc = (C - c0) < 8 ? (C - c0) : 8;
+  const int rowlen = nc * HW, pitch = 8 * HW + 1;
+  for (int e = t; e < 64 * rowlen; e += 256) {
+    const int kl = e / rowlen, r = e - kl * rowlen;
+    if (kl < nk) tile[kl * pitch + r] = src[((int64_t)(k0 + kl) * C + c0) * HW + r];
+  }
+  __syncthreads();
+  const int nkp = (Bp - k0) < 64 ? (Bp - k0) : 64;
+  for (int e = t; e < rowlen * 64; e += 256) {
+    const int kl = e & 63, r = e >> 6;   // r = cl*HW + p
+    if (kl >= nkp) continue;
+    const int cl = r / HW, pp = r - cl * HW;
+    float v = kl < nk ? tile[kl * pitch + r] : 0.f;
+    bf16_t* dp = dst + ((int64_t)pp * C + c0 + cl) * Kg + k0 + kl;
+    for (int q = 0; q < nplanes; ++q) {
+      const bf16_t h = f2bf(v);
+      dp[(int64_t)q * plane] = h;
+      v -= bf2f(h);
+    }
+  }
+  if (blockIdx.x == 0)  // zero tail columns [Bp, Kg) of the rows this block owns
+    for (int r = 0; r < rowlen; ++r) {
+      const int cl = r / HW, pp = r - cl * HW;
+      for (int j = Bp + t; j < Kg; j += 256)
+        for (int q = 0; q < nplanes; ++q) dst[(int64_t)q * plane + ((int64_t)pp * C + c0 + cl) * Kg + j] = 0;
+    }
+}
+
 template <typename T>
 __global__ void bias_cast_kernel(const float* __restrict__ ws, const float* __restrict__ bias, T* __restrict__ out, int64_t M,
                                  int K, int ld) {
@@ -1083,10 +1238,36 @@ extern "C" int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, 
   XR_CHECK_ARG(src && dst && (nplanes == 1 || nplanes == 3), "xr_pack_weight: null pointer or nplanes not in {1,3}");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Bp % 8 == 0 && Kg % 64 == 0 && Kg >= taps * Bp,
                "xr_pack_weight: bad dims A1=%d A2=%d taps=%d B=%d Bp=%d Kg=%d", A1, A2, taps, B, Bp, Kg);
+  hipStream_t st_h = (hipStream_t)stream;
   const int64_t total = (int64_t)A1 * A2 * Kg;
+  if (A2 == 1 && st_ == 1 && taps <= 64 && A1 <= 65535) {
+    if (sb == taps && sa1 == (int64_t)B * taps) {  // parameter [A][B][taps]
+      hipLaunchKernelGGL(pack_fwdform_kernel, dim3(cdiv(Bp, 64), A1), dim3(256), (size_t)64 * taps * sizeof(float), st_h, src,
+                         (bf16_t*)dst, nplanes, taps, B, Bp, Kg, total);
+      XR_CHECK_LAUNCH("xr_pack_weight");
+      return XR_OK;
+    }
+    if (sa1 == taps && sb == (int64_t)A1 * taps) {  // parameter [B][A][taps]
+      hipLaunchKernelGGL(pack_dgradform_kernel, dim3(cdiv(Bp, 64), cdiv(A1, 4)), dim3(256),
+                         (size_t)64 * (4 * taps + 1) * sizeof(float), st_h, src, (bf16_t*)dst, nplanes, taps, A1, B, Bp, Kg, total);
+      XR_CHECK_LAUNCH("xr_pack_weight");
+      return XR_OK;
+    }
+  }
+  if (taps == 1 && sa1 == 1 && sa2 == (int64_t)A1 && sb == (int64_t)A1 * A2 && A1 <= 64 && A2 <= 65535 * 8) {
+    // Linear dgrad pack: A1 = HW, A2 = C, B = K
+    const size_t smem = (size_t)64 * (8 * A1 + 1) * sizeof(float);
+    if (smem > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_lindgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem);
+    hipLaunchKernelGGL(pack_lindgrad_kernel, dim3(cdiv(Bp, 64), cdiv(A2, 8)), dim3(256), smem, st_h, src, (bf16_t*)dst, nplanes, A1,
+                       A2, B, Bp, Kg, total);
+    XR_CHECK_LAUNCH("xr_pack_weight");
+    return XR_OK;
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, nplanes, A2, taps, B, Bp, Kg, sa1, sa2, st_, sb, total);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, st_h, src, (bf16_t*)dst, nplanes, A2, taps, B, Bp, Kg, sa1, sa2, st_, sb, total);
   XR_CHECK_LAUNCH("xr_pack_weight");
   return XR_OK;
 }
@@ -1097,6 +1278,33 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   XR_CHECK_ARG(packed && dst && nslices >= 1, "xr_unpack_wgrad: null pointer / nslices < 1");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Kg >= taps * Bp, "xr_unpack_wgrad: bad dims");
   const int64_t total = (int64_t)A1 * A2 * taps * B;
+  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 16 && taps <= 64 && A1 <= 65535) {
+    // wide transposes (Linear viewed as a 7x7 conv: 49 taps): LDS-tiled so both sides stay coalesced
+    hipLaunchKernelGGL(unpack_fwdform_kernel, dim3(cdiv(B, 64), A1), dim3(256), (size_t)64 * taps * sizeof(float),
+                       (hipStream_t)stream, packed, dst, taps, B, Bp, Kg, accumulate & 1, nslices, (int64_t)A1 * Kg);
+    XR_CHECK_LAUNCH("xr_unpack_wgrad");
+    return XR_OK;
+  }
+  if (B % 4 == 0 && Bp % 4 == 0 && Kg % 4 == 0) {
+    const int64_t total4 = total / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    // few outputs but many slices (the 64-channel layers): spread the slices over blockIdx.y and meet by atomics
+    int groups = 1;
+    if (blocks < 512 && nslices > 16) groups = (nslices + 15) / 16;
+    const int spg = (nslices + groups - 1) / groups;
+    groups = (nslices + spg - 1) / spg;
+    if (groups > 1 && !(accumulate & 1)) {
+      if (hipMemsetAsync(dst, 0, (size_t)total * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        xr_set_error("xr_unpack_wgrad: memset failed");
+        return XR_E_LAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(unpack_wgrad4_kernel, dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, packed, dst, A2, taps, B / 4,
+                       Bp, Kg, sa1, sa2, st_, sb, accumulate, nslices, (int64_t)A1 * A2 * Kg, total4, spg);
+    XR_CHECK_LAUNCH("xr_unpack_wgrad");
+    return XR_OK;
+  }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, dst, A2, taps, B, Bp,

@@ -193,6 +193,7 @@ struct AffP {
   const void* x; const float* scale; const float* shift; const void* res; const float* alpha; int act;
   void* y; const void* dy; float* red; const float* coef; void* dx; void* dres;
   int coef_per_group;  // scale/shift are [G][C] (1) or [C] (0)
+  const void* dx_add;  // optional: added to dx (gradient arriving through an identity branch of the same input)
 };
 
 template <typename T>
@@ -349,11 +350,13 @@ __global__ __launch_bounds__(NT) void affine_act_bwd_apply_kernel(AffP p, Geo ge
   const T* dy = reinterpret_cast<const T*>(p.dy) + gbase;
   T* dx = p.dx ? reinterpret_cast<T*>(p.dx) + gbase : nullptr;
   T* dres = p.dres ? reinterpret_cast<T*>(p.dres) + gbase : nullptr;
+  const T* dxa = p.dx_add ? reinterpret_cast<const T*>(p.dx_add) + gbase : nullptr;
   for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
-    float v[8], rv[8], d[8], o[8], dzv[8];
+    float v[8], rv[8], d[8], o[8], dzv[8], ex[8];
     ld8(x + (size_t)r * geo.C, v);
     ld8(dy + (size_t)r * geo.C, d);
     if (res) ld8(res + (size_t)r * geo.C, rv);
+    if (dxa) ld8(dxa + (size_t)r * geo.C, ex);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float z = v[e] * sc[e] + sh[e];
@@ -361,6 +364,7 @@ __global__ __launch_bounds__(NT) void affine_act_bwd_apply_kernel(AffP p, Geo ge
       const float dz = d[e] * act_grad(z, al[e], p.act);
       dzv[e] = dz;
       o[e] = cA[e] * dz + cB[e] * v[e] + cC[e];
+      if (dxa) o[e] += ex[e];
     }
     if (dx) st8(dx + (size_t)r * geo.C, o);
     if (dres) st8(dres + (size_t)r * geo.C, dzv);
@@ -627,7 +631,7 @@ extern "C" int xr_affine_act(int dtype, const void* x, const float* scale, const
   if (int e = check_geo("xr_affine_act", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && y, "xr_affine_act: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act: PReLU needs alpha");
-  AffP p{x, scale, shift, res, alpha, act, y, nullptr, nullptr, nullptr, nullptr, nullptr, coef_per_group};
+  AffP p{x, scale, shift, res, alpha, act, y, nullptr, nullptr, nullptr, nullptr, nullptr, coef_per_group, nullptr};
   Geo geo = make_geo(G, rows, C, 4096);
   if (dtype == XR_BF16) return launch_aff<bf16_t>(affine_act_kernel<bf16_t>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
   return launch_aff<float>(affine_act_kernel<float>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
@@ -639,7 +643,7 @@ extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* s
   if (int e = check_geo("xr_affine_act_bwd_reduce", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && dy && red, "xr_affine_act_bwd_reduce: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_reduce: PReLU needs alpha");
-  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, red, nullptr, nullptr, nullptr, coef_per_group};
+  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, red, nullptr, nullptr, nullptr, coef_per_group, nullptr};
   Geo geo = make_geo(G, rows, C, 2048);
   const size_t smem = (size_t)(geo.rpb > 12 ? geo.rpb : 12) * C * sizeof(float);
   if (dtype == XR_BF16)
@@ -665,11 +669,11 @@ extern "C" int xr_reduce_groups(const float* red, float* out, int NV, int G, int
 
 extern "C" int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                                        const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
-                                       int G, int rows, int C, int coef_per_group, void* stream) {
+                                       int G, int rows, int C, int coef_per_group, const void* dx_add, void* stream) {
   if (int e = check_geo("xr_affine_act_bwd_apply", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && dy && (dx || dres), "xr_affine_act_bwd_apply: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_apply: PReLU needs alpha");
-  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, dres, coef_per_group};
+  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, dres, coef_per_group, dx_add};
   Geo geo = make_geo(G, rows, C, 4096);
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");

@@ -61,10 +61,10 @@ class bottleneck_IR(Module):
             Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False), PReLU(depth),
             Conv2d(depth, depth, (3, 3), stride, 1, bias=False), BatchNorm2d(depth))
 
-    def _conv_prelu_conv(self, x):
-        """BN -> conv3x3 -> PReLU -> conv3x3(stride); the PReLU backward rides in the second conv's dgrad epilogue."""
+    def _conv_prelu_conv(self, b1):
+        """(BN output) -> conv3x3 -> PReLU -> conv3x3(stride); the PReLU backward rides in the second conv's dgrad epilogue."""
         rl = self.res_layer
-        y1 = rl[1].f(rl[0].f(x))
+        y1 = rl[1].f(b1)
         c2 = rl[3]
         return ops.prelu_conv2d(y1, rl[2].weight, c2.weight, c2.stride[0], c2.padding[0])
 
@@ -74,10 +74,12 @@ class bottleneck_IR(Module):
         return self.shortcut_layer.f(x)
 
     def f(self, x):
-        sc = self._shortcut(x)
-        rl = self.res_layer
-        r = self._conv_prelu_conv(x)
-        return rl[4].f(r, res=sc)
+        # the block input feeds both the BN of the residual branch and the shortcut: route the shortcut through the
+        # BN op's pass-through output so the two input gradients are summed inside its backward kernel
+        b1, xs = self.res_layer[0].f_pass(x)
+        sc = self._shortcut(xs)
+        r = self._conv_prelu_conv(b1)
+        return self.res_layer[4].f(r, res=sc)
 
     def forward(self, x):
         return leave(self.f(enter(x)))
@@ -95,9 +97,10 @@ class bottleneck_IR_SE(bottleneck_IR):
             SEModule(depth, 16))
 
     def f(self, x):
-        sc = self._shortcut(x)
         rl = self.res_layer
-        y2 = self._conv_prelu_conv(x)
+        b1, xs = rl[0].f_pass(x)
+        sc = self._shortcut(xs)
+        y2 = self._conv_prelu_conv(b1)
         return ops.bn_se_add(y2, rl[4], rl[5], sc)   # BatchNorm + SE + shortcut add in one elementwise pass
 
 

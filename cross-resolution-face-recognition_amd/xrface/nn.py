@@ -68,6 +68,16 @@ class _BNMixin:
                             mom, self.eps)
 
 
+    def f_pass(self, buf):
+        """(bn(buf), buf'): buf' aliases buf and carries the identity-branch gradient into this norm's backward."""
+        training = self.training or not self.track_running_stats
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        mom = 0.1 if self.momentum is None else self.momentum
+        return ops.norm_act_pass(buf, self.weight, self.bias, self.running_mean, self.running_var, "bn", None, training, mom,
+                                 self.eps)
+
+
 class BatchNorm2d(_BNMixin, nn.BatchNorm2d):
     def forward(self, x):
         return leave(self.f(enter(x)))

@@ -469,9 +469,10 @@ class _NormAct(Function):
     ``training``), 'none' (activation / residual add only)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False):
         x = _c(x)
         N, H, W, C = x.shape
+        ctx.passthrough = passthrough
         if res is not None:
             res = _c(res)
             assert res.shape == x.shape and res.dtype == x.dtype
@@ -513,15 +514,23 @@ class _NormAct(Function):
         ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
         ctx.prefs = (gamma, beta, alpha)
         ctx.per_img = (per_img, pg, (N // pg) * H * W)
+        if passthrough:  # second output aliases the input: its gradient is folded into dx by the apply kernel
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x, res, scale, shift, mean, invstd, gm, al, rmean, rvar = ctx.saved_tensors
         mode, a, stats, G, rows, C, eps, has_g, has_b, has_a = ctx.meta
+        if dy is None:
+            dy = torch.zeros_like(x)
         dy = _c(dy)
         if dy.dtype != x.dtype:
             dy = dy.to(x.dtype)
+        if dpass is not None:
+            dpass = _c(dpass)
+            if dpass.dtype != x.dtype:
+                dpass = dpass.to(x.dtype)
         f32 = dict(dtype=torch.float32, device=x.device)
         per_img, N_, HW_ = ctx.per_img
         if per_img:
@@ -573,8 +582,14 @@ class _NormAct(Function):
         dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[5]) else None
         if dx is not None or dres is not None:
             lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
-                                        ptr(dres), G, rows, C, 1, stream())
-        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None
+                                        ptr(dres), G, rows, C, 1, ptr(dpass), stream())
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None
+
+
+def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", act=None, training=True, momentum=0.1, eps=EPS):
+    """(norm(x), x'): x' aliases x; route identity branches (block shortcuts) through x' and the two gradients of x are
+    summed inside the norm's backward apply kernel instead of by a separate elementwise pass."""
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, True)
 
 
 def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,
@@ -627,7 +642,7 @@ class _SEScaleAdd(Function):
                              ctx.inv_hw, stream())
         dr = torch.empty_like(r)
         lib.xr_affine_act_bwd_apply(dt(r), ptr(r), None, None, None, None, ACT_NONE, ptr(dy), ptr(coef), ptr(dr), None, N, H * W, C,
-                                    1, stream())
+                                    1, None, stream())
         w1, w2 = ctx.wrefs
         t1, t2 = _direct(w1), _direct(w2)
         dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), r.device)
@@ -720,7 +735,7 @@ class _BnSeAdd(Function):
         if ctx.needs_input_grad[0]:
             dy = torch.empty_like(y)
             lib.xr_affine_act_bwd_apply(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(coef), ptr(dy), None, N, HW,
-                                        C, 1, stream())
+                                        C, 1, None, stream())
         dw1 = dw2 = None
         if ctx.needs_input_grad[5]:
             t1, t2 = _direct(w1), _direct(w2)

