@@ -58,6 +58,7 @@ struct IgemmP {
   const void* ep_src;
   const float* ep_alpha;
   float* ep_dalpha;
+  int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
 };
 
 // decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
@@ -154,6 +155,7 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 // lane-linear, so the XOR swizzle is applied to the SOURCE chunk each lane fetches.
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT>
 __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void igemm_kernel(IgemmP p) {
+  const bool g_prio = p.prio != 0;
   constexpr int NBUF = DMA ? DMA : 1;
   static_assert(DMA == 0 || (FAST && MODE == 0), "DMA staging needs the FAST bf16 path");
   static_assert(BKT == 64 || (BKT == 32 && DMA != 0), "32-element stages exist for the DMA path only");
@@ -453,10 +455,12 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void i
 #pragma unroll
         for (int s = 0; s < NS; ++s) fb[j][s] = *reinterpret_cast<const bf16x8_t*>(sB + s * BN * ROWB + off);
       }
+      if (g_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
+      if (g_prio) __builtin_amdgcn_s_setprio(0);
     }
   };
 
@@ -610,7 +614,7 @@ constexpr size_t igemm_smem() {
   return ops > stg ? ops : stg;
 }
 
-int g_tune[8] = {3, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA staging, 3 auto; [2] != 0 disables wgrad FAST
+int g_tune[8] = {3, 1, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
 int launch_igemm_f(IgemmP& p, hipStream_t st);
@@ -1338,9 +1342,9 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, g_tune[4]};
   hipStream_t st = (hipStream_t)stream;
-  const bool wide = K > 64;
+  const bool wide = K > 64 && g_tune[3] == 0;
   if (dtype == XR_BF16) {
     if (wide) return transposed ? launch_igemm<0, 128, 128, 2, true>(p, st) : launch_igemm<0, 128, 128, 2, false>(p, st);
     return transposed ? launch_igemm<0, 128, 64, 4, true>(p, st) : launch_igemm<0, 128, 64, 4, false>(p, st);

@@ -30,9 +30,10 @@ def timeit(fn, reps=8):
 
 
 def main():
-    variants = [(int(a), int(b)) for a, b in (v.split(",") for v in os.environ.get("VARIANTS", "1,1;2,2").split(";"))]
+    variants = [tuple(int(q) for q in v.split(",")) for v in os.environ.get("VARIANTS", "3,1,0").split(";")]
+    variants = [tuple(list(v) + [0] * (4 - len(v))) for v in variants]
     dtype = torch.bfloat16
-    print(f"{'shape':28s} " + " ".join(f"{'fwd/dgr/wgr nb=%d,%d' % v:>26s}" for v in variants))
+    print(f"{'shape':28s} " + " ".join(f"{'fwd/dgr/wgr %d,%d,%d,%d' % v:>26s}" for v in variants))
     tot = {v: [0.0, 0.0, 0.0] for v in variants}
     for C, K, H, st in SHAPES:
         Ho = (H + 2 - 3) // st + 1
@@ -50,7 +51,7 @@ def main():
         row = f"{C:3d}->{K:3d} @{H:3d} s{st} {flops/1e9:6.1f}GF "
         ref = None
         for v in variants:
-            lib.xr_tune(0, v[0]); lib.xr_tune(2, 1 - v[1])
+            lib.xr_tune(0, v[0]); lib.xr_tune(2, 1 - v[1]); lib.xr_tune(3, v[2]); lib.xr_tune(4, v[3])
             f = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None, None, stream()))
             d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None, None, stream()))
             g = timeit(lambda: lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slab), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, K, kg, split, stream()))
