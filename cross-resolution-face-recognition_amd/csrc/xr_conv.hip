@@ -475,7 +475,10 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void i
     for (int kk = kbeg; kk < nk; ++kk) {
       if (kk + 1 < nk) {
         if constexpr (RA + RB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (RA + RB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (RA + RB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        static_assert(RA + RB == 8 || RA + RB == 6 || RA + RB == 4 || RA + RB == 3, "unexpected DMA instruction count");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -614,7 +617,7 @@ constexpr size_t igemm_smem() {
   return ops > stg ? ops : stg;
 }
 
-int g_tune[8] = {3, 1, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA
+int g_tune[8] = {3, 1, 0, 0, 1, 1, 18, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages)
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
 int launch_igemm_f(IgemmP& p, hipStream_t st);
@@ -633,9 +636,10 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
   if constexpr (MODE == 0) {
     // LDS-DMA staging pays once the K loop is long enough to amortise the lower occupancy (2 x 32 KB stages per WG):
     // measured cross-over between the 128- and 256-channel 3x3 layers (18 vs 36 stages)
-    const bool dma = g_tune[0] == 2 || (g_tune[0] == 3 && p.Kg / BK >= 32);
+    const bool dma = g_tune[0] == 2 || (g_tune[0] == 3 && p.Kg / BK >= g_tune[6]);
     if (fast && g_tune[0] == 4) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 3>(p, st);
     if (fast && g_tune[0] == 5) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 2, 32>(p, st);
+    if (fast && g_tune[0] == 6) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 3, 32>(p, st);
     if (fast && dma) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 2>(p, st);
   }
   if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 0>(p, st);
@@ -694,6 +698,7 @@ struct WgradP {
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c, tiles_all;
   FastDiv fd_howo, fd_wo;
   int a64, b64, c64;            // 64 pixels = a64 images + b64 rows + c64 columns (per-step cursor advance)
+  int prio;                     // raise wave priority around the MFMA clusters (tuning knob 5)
   unsigned in_bytes, dy_bytes;  // buffer-descriptor extents (FAST path)
 };
 
@@ -914,10 +919,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int s = 0; s < NS; ++s) fb[j][s] = tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
+      if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
+      if (p.prio) __builtin_amdgcn_s_setprio(0);
     }
   };
 
@@ -1364,7 +1371,7 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
                ldy);
   XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_wgrad: bad Kg=%d", Kg);
   XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
-  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0};
+  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, g_tune[5], 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool tall = K > 64;
   if (dtype == XR_BF16) {

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""In-process A/B of the IR-SE-50 bf16 training step under different tuning knobs (interleaved rounds; one device)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "cross-resolution-face-recognition_amd"))
+import torch
+import xrface
+from xrface import parallel, ops
+from xrface._lib import lib
+from xrface.loss.loss import CrossEntropyLoss
+from xrface.model.model_irse import IR_SE_50
+import bench
+
+dev = torch.device("cuda:0")
+xrface.set_compute_dtype(torch.bfloat16)
+torch.manual_seed(0)
+model = IR_SE_50([112, 112]).to(dev).train()
+flat = parallel.FlatParams(model.parameters())
+opt = parallel.FusedSGD(flat, lr=0.01, momentum=0.9, weight_decay=5e-4)
+crit = CrossEntropyLoss()
+x, y = bench.synth_batch(int(os.environ.get("N", 256)), dev, 0)
+
+
+def step():
+    opt.zero_grad(); crit(model(x), y).backward(); opt.step()
+
+
+# VARIANTS="name:knob=val,knob=val;..." ; special key: wb = ops wgrad_blocks
+variants = []
+for spec in os.environ.get("VARIANTS", "base:;wprio:5=1").split(";"):
+    name, kv = spec.split(":")
+    variants.append((name, [tuple(p.split("=")) for p in kv.split(",") if p]))
+defaults = {0: 3, 2: 0, 3: 0, 4: 1, 5: 1, 6: 18}
+
+
+def apply(kvs):
+    for k, v in defaults.items():
+        lib.xr_tune(k, v)
+    ops._cfg["wgrad_blocks"] = 512
+    for k, v in kvs:
+        if k == "wb":
+            ops._cfg["wgrad_blocks"] = int(v)
+        else:
+            lib.xr_tune(int(k), int(v))
+
+
+for _ in range(3):
+    step()
+res = {n: [] for n, _ in variants}
+for rnd in range(int(os.environ.get("ROUNDS", 4))):
+    for name, kvs in variants:
+        apply(kvs)
+        step(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        res[name].append((time.perf_counter() - t0) / 4 * 1e3)
+for name, v in res.items():
+    v = sorted(v)
+    print(f"{name:12s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f}  max {v[-1]:.3f}")
