@@ -12,74 +12,13 @@
 //
 // Replaces the ATen conv calls issued by /root/reference model/FSRnet.py:79,85,110,312,318,345,351,384,391,
 // 392,432,436,439; SUPER_RESOLUTION/model/model_irse.py:56-60,140,147; model/resnet.py:9-16,158,170.
-#include "xr_common.h"
+#include "xr_conv_p.h"
 #include <type_traits>
 
 namespace {
 
 constexpr int BK = 64;        // reduction elements per LDS stage
 constexpr int NT = 256;       // threads per workgroup (4 waves)
-
-// division by a launch-invariant 32-bit divisor: q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(magic, n)
-// (Granlund-Montgomery round-up form, exact for every 32-bit n); d == 1 is special-cased.
-struct FastDiv {
-  unsigned magic, shift, d;
-};
-static FastDiv make_fd(unsigned d) {
-  FastDiv f;
-  f.d = d;
-  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
-  unsigned l = 0;
-  while ((1ull << l) < d) ++l;
-  f.magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
-  f.shift = l;
-  return f;
-}
-__device__ __forceinline__ int fdiv(const FastDiv& f, int n) {
-  if (f.d <= 1) return n;
-  const unsigned un = (unsigned)n;
-  const unsigned t = __umulhi(f.magic, un);
-  return (int)((t + ((un - t) >> 1)) >> (f.shift - 1));
-}
-
-struct IgemmP {
-  const void* in;
-  const bf16_t* w;  // NS planes of [K][Kg] bf16, plane stride K*Kg
-  const float* bias;
-  void* out;
-  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo, M, tiles_n;
-  int cls, tpc, Mc;   // class mode (transposed gather, stride > 1): output pixels grouped by (ho % s, wo % s)
-  float* ws;          // split-K fp32 workspace [M][ldo] (atomics) or nullptr
-  int ksplit;         // K-stages per blockIdx.y slice (split-K), 0 = no split
-  FastDiv fd_howo, fd_wo, fd_c, fd_s, fd_hqwq, fd_wq, fd_tn, fd_st;
-  unsigned in_bytes, w_bytes;  // buffer-descriptor extents (FAST path)
-  // fused PReLU backward in the epilogue (dgrad of conv(prelu(y))): out = acc * (y > 0 ? 1 : alpha[c]),
-  // dalpha[c] += sum acc * y * [y <= 0];  ep_src = y laid out like `out`
-  const void* ep_src;
-  const float* ep_alpha;
-  float* ep_dalpha;
-  int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
-};
-
-// decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
-template <bool TR>
-__device__ __forceinline__ void decode_pixel(int m, int M, const FastDiv& fd_howo, const FastDiv& fd_wo, int HW, int stride,
-                                             int pad, bool& valid, int& nb, int& oh0, int& ow0) {
-  valid = m < M;
-  int mm = valid ? m : 0;
-  int n = fdiv(fd_howo, mm);
-  int rem = mm - n * (int)fd_howo.d;
-  int ho = fdiv(fd_wo, rem);
-  int wo = rem - ho * (int)fd_wo.d;
-  nb = n * HW;
-  if (TR) {
-    oh0 = ho + pad;
-    ow0 = wo + pad;
-  } else {
-    oh0 = ho * stride - pad;
-    ow0 = wo * stride - pad;
-  }
-}
 
 // input coordinate for tap (r,s); returns validity and pixel offset hi*W+wi
 template <bool TR>
@@ -617,7 +556,9 @@ constexpr size_t igemm_smem() {
   return ops > stg ? ops : stg;
 }
 
-int g_tune[8] = {3, 1, 0, 0, 1, 1, 18, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages)
+}  // namespace
+int g_tune[8] = {3, 1, 0, 0, 1, 1, 18, 1};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible
+namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
 int launch_igemm_f(IgemmP& p, hipStream_t st);
@@ -1351,6 +1292,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
            N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, g_tune[4]};
   hipStream_t st = (hipStream_t)stream;
+  if (xr_igemm8_eligible(p, dtype, transposed)) return xr_igemm8_launch(p, transposed, st);
   const bool wide = K > 64 && g_tune[3] == 0;
   if (dtype == XR_BF16) {
     if (wide) return transposed ? launch_igemm<0, 128, 128, 2, true>(p, st) : launch_igemm<0, 128, 128, 2, false>(p, st);

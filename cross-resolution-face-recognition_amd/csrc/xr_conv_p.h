@@ -1,0 +1,73 @@
+// xr_conv_p.h -- launch parameters and index helpers shared by the implicit-GEMM convolution kernels
+// (xr_conv.hip: 4-wave 128-row tiles; xr_conv8.hip: 8-wave 256x256 tiles).
+#pragma once
+#include "xr_common.h"
+
+// division by a launch-invariant 32-bit divisor: q = (t + ((n - t) >> 1)) >> (l - 1), t = mulhi(magic, n)
+// (Granlund-Montgomery round-up form, exact for every 32-bit n); d == 1 is special-cased.
+struct FastDiv {
+  unsigned magic, shift, d;
+};
+static inline FastDiv make_fd(unsigned d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1) { f.magic = 0; f.shift = 0; return f; }
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.magic = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+  f.shift = l;
+  return f;
+}
+__device__ __forceinline__ int fdiv(const FastDiv& f, int n) {
+  if (f.d <= 1) return n;
+  const unsigned un = (unsigned)n;
+  const unsigned t = __umulhi(f.magic, un);
+  return (int)((t + ((un - t) >> 1)) >> (f.shift - 1));
+}
+
+struct IgemmP {
+  const void* in;
+  const bf16_t* w;  // NS planes of [K][Kg] bf16, plane stride K*Kg
+  const float* bias;
+  void* out;
+  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo, M, tiles_n;
+  int cls, tpc, Mc;   // class mode (transposed gather, stride > 1): output pixels grouped by (ho % s, wo % s)
+  float* ws;          // split-K fp32 workspace [M][ldo] (atomics) or nullptr
+  int ksplit;         // K-stages per blockIdx.y slice (split-K), 0 = no split
+  FastDiv fd_howo, fd_wo, fd_c, fd_s, fd_hqwq, fd_wq, fd_tn, fd_st;
+  unsigned in_bytes, w_bytes;  // buffer-descriptor extents (FAST path)
+  // fused PReLU backward in the epilogue (dgrad of conv(prelu(y))): out = acc * (y > 0 ? 1 : alpha[c]),
+  // dalpha[c] += sum acc * y * [y <= 0];  ep_src = y laid out like `out`
+  const void* ep_src;
+  const float* ep_alpha;
+  float* ep_dalpha;
+  int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
+};
+
+// decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin
+template <bool TR>
+__device__ __forceinline__ void decode_pixel(int m, int M, const FastDiv& fd_howo, const FastDiv& fd_wo, int HW, int stride,
+                                             int pad, bool& valid, int& nb, int& oh0, int& ow0) {
+  valid = m < M;
+  int mm = valid ? m : 0;
+  int n = fdiv(fd_howo, mm);
+  int rem = mm - n * (int)fd_howo.d;
+  int ho = fdiv(fd_wo, rem);
+  int wo = rem - ho * (int)fd_wo.d;
+  nb = n * HW;
+  if (TR) {
+    oh0 = ho + pad;
+    ow0 = wo + pad;
+  } else {
+    oh0 = ho * stride - pad;
+    ow0 = wo * stride - pad;
+  }
+}
+
+
+extern int g_tune[8];
+
+// 8-wave 256x256 tile path (xr_conv8.hip).  xr_igemm8_eligible() decides from the problem alone; the launcher returns
+// XR_OK or a negative error code like every other launcher.
+bool xr_igemm8_eligible(const IgemmP& p, int dtype, int transposed);
+int xr_igemm8_launch(IgemmP& p, int transposed, hipStream_t st);

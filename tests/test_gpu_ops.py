@@ -81,6 +81,85 @@ def test_conv2d_fwd_bwd(case, dtype):
         assert rel(bg.grad, br.grad) < tol
 
 
+CONV8_CASES = [
+    # N, C, H, W, K, R, stride, pad, bias  -- the 8-wave 256x256 kernel forced on (xr_tune knob 7 = 2)
+    (2, 64, 14, 14, 256, 3, 1, 1, False),    # 392 rows: one full + one ragged row tile
+    (3, 128, 10, 10, 264, 3, 1, 1, True),    # two column tiles, the second 8 wide; bias
+    (2, 64, 28, 28, 128, 3, 2, 1, False),    # stride-2 gather (dgrad falls back to the class-mode kernel)
+    (5, 192, 8, 8, 72, 1, 1, 0, True),       # 1x1, three channel chunks per tap
+    (1, 64, 16, 16, 512, 3, 1, 1, False),    # exactly one row tile, two column tiles
+]
+
+
+@pytest.mark.parametrize("case", CONV8_CASES)
+def test_conv2d_8wave_kernel(case):
+    """xr_conv8.hip (8-wave ping-pong tile) against the fp32 CPU conv: forward, input gradient (same kernel, transposed
+    gather) and -- unchanged kernel, sanity only -- the weight gradient."""
+    from xrface import ops
+    from xrface._lib import lib
+    N, C, H, W, K, R, stride, pad, bias = case
+    x = rnd(f"c8x{case}", N, C, H, W).bfloat16().float()
+    w = rnd(f"c8w{case}", K, C, R, R, scale=(C * R * R) ** -0.5)
+    b = rnd(f"c8b{case}", K, scale=0.1) if bias else None
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    y_ref = F.conv2d(xr, wr, br, stride, pad)
+    gy = rnd(f"c8g{case}", *y_ref.shape)
+    y_ref.backward(gy)
+    lib.xr_tune(7, 2)
+    try:
+        xg = x.to(DEV).requires_grad_(True)
+        wg = w.to(DEV).requires_grad_(True)
+        bg = b.to(DEV).requires_grad_(True) if bias else None
+        yb = ops.conv2d(ops.enter(xg, torch.bfloat16), wg, bg, stride, pad)
+        y = ops.leave(yb, K)
+        y.backward(gy.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        lib.xr_tune(7, 1)
+    tol = TOL[torch.bfloat16]
+    assert rel(y, y_ref) < tol
+    assert rel(xg.grad, xr.grad) < tol
+    assert rel(wg.grad, wr.grad) < tol
+    # and bit-for-bit stable against the 4-wave kernel up to accumulation order: compare on the same inputs
+    lib.xr_tune(7, 0)
+    try:
+        y4 = ops.leave(ops.conv2d(ops.enter(x.to(DEV), torch.bfloat16), w.to(DEV), b.to(DEV) if bias else None, stride, pad), K)
+    finally:
+        lib.xr_tune(7, 1)
+    assert rel(y, y4) < 1e-2
+
+
+def test_conv2d_8wave_prelu_backward_epilogue():
+    """dgrad of conv(prelu(y)) with the PReLU backward fused into the 8-wave kernel's epilogue."""
+    from xrface import ops
+    from xrface._lib import lib
+    N, C, H, K = 2, 256, 14, 64
+    y0 = rnd("c8py", N, C, H, H).bfloat16().float()
+    al = rnd("c8pa", C, scale=0.3).abs() + 0.05
+    w = rnd("c8pw", K, C, 3, 3, scale=(C * 9) ** -0.5)
+    yr, ar, wr = y0.clone().requires_grad_(True), al.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    out_ref = F.conv2d(F.prelu(yr, ar), wr, None, 1, 1)
+    g = rnd("c8pg", *out_ref.shape)
+    out_ref.backward(g)
+    res = {}
+    for knob in (2, 0):
+        lib.xr_tune(7, knob)
+        try:
+            yg, ag, wg = y0.to(DEV).requires_grad_(True), al.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+            out = ops.leave(ops.prelu_conv2d(ops.enter(yg, torch.bfloat16), ag, wg, 1, 1), K)
+            out.backward(g.to(DEV))
+            torch.cuda.synchronize()
+        finally:
+            lib.xr_tune(7, 1)
+        res[knob] = (out.detach().cpu(), yg.grad.cpu(), ag.grad.cpu())
+        assert rel(out, out_ref) < TOL[torch.bfloat16]
+        assert rel(yg.grad, yr.grad) < TOL[torch.bfloat16]
+        assert rel(ag.grad, ar.grad) < 4e-2
+    assert rel(res[2][1], res[0][1]) < 1e-2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_transpose2d_k7s4(dtype):
     from xrface import ops

@@ -30,6 +30,7 @@ variants = []
 for spec in os.environ.get("VARIANTS", "base:;wprio:5=1").split(";"):
     name, kv = spec.split(":")
     variants.append((name, [tuple(p.split("=")) for p in kv.split(",") if p]))
+cfg0 = dict(ops._cfg)
 defaults = {0: 3, 2: 0, 3: 0, 4: 1, 5: 1, 6: 18}
 
 
@@ -37,8 +38,11 @@ def apply(kvs):
     for k, v in defaults.items():
         lib.xr_tune(k, v)
     ops._cfg["wgrad_blocks"] = 512
+    ops._cfg.update(cfg0)
     for k, v in kvs:
-        if k == "wb":
+        if k.startswith("cfg."):
+            ops._cfg[k[4:]] = int(v)
+        elif k == "wb":
             ops._cfg["wgrad_blocks"] = int(v)
         else:
             lib.xr_tune(int(k), int(v))
