@@ -24,13 +24,20 @@
 namespace {
 
 constexpr int NT8 = 512;
-constexpr int BM8 = 256, BN8 = 256;
-constexpr int BUF8 = (BM8 + BN8) * 128;   // one K-tile of both operands: 64 KiB
-constexpr int BOFF8 = BM8 * 128;          // B rows follow the A rows inside a buffer
 typedef unsigned v4u8_t __attribute__((ext_vector_type(4)));
 #define XR8_OOR 0x80000000u
 
-#define XR8_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void vmcnt_le() {  // wait until at most N of this wave's vector-memory operations are pending
+  static_assert(N >= 0 && N <= 6, "unexpected DMA count");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
 
 __device__ __forceinline__ bf16x8_t lds_read16(unsigned addr) {
   v4u8_t v;
@@ -38,12 +45,38 @@ __device__ __forceinline__ bf16x8_t lds_read16(unsigned addr) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <bool TR>
+// Tile configuration: WRN wave rows x WCN = 8 / WRN wave columns; a wave owns (2 * MB * 16) rows x 64 columns, one
+// phase = one quadrant of MB x 2 MFMA blocks x 2 k-steps.
+//   <2, 4>: 256 x 256 (K % 256 == 0, many rows)   <4, 2>: 256 x 128 (128-channel layers)   <2, 2>: 128 x 256 (7x7 maps)
+// MB1 < MB trims the second M-half of every wave to MB1 blocks: the LDS image keeps its 2 * MB * 16 rows per wave row (the
+// trimmed rows are zero-filled and never multiplied), the tile covers WRN * (MB + MB1) * 16 output rows.  <2, 4, 3> = 224
+// rows turns the 196 (x 256-row) tiles of the 14x14 layers at batch 256 into 224 tiles of 7/8 the work: one round on 256 CUs
+// either way.
+template <int WRN, int MB, int MB1 = MB>
+struct Cfg8 {
+  static constexpr int WCN = 8 / WRN;
+  static constexpr int QR = MB * 16, WTR = 2 * QR;     // quadrant / wave-tile rows (LDS image)
+  static constexpr int WV = (MB + MB1) * 16;           // output rows per wave row
+  static constexpr int BMV = WRN * WV;                 // output rows per tile
+  static constexpr int BM = WRN * WTR, BN = WCN * 64;
+  static constexpr int BUF = (BM + BN) * 128;           // one K-tile of both operands
+  static constexpr int BOFF = BM * 128;                 // B rows follow the A rows inside a buffer
+  static constexpr int PA = WRN * QR / 64, PB = WCN / 2;  // 1-KiB DMA pieces per wave per A / B quarter tile
+  static constexpr int IMG = WTR * 128;                 // wave-private epilogue image
+  static_assert(2 * BUF >= 8 * IMG, "epilogue images must fit in the operand buffers");
+};
+
+template <bool TR, int WRN, int MB, int MB1>
 __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
+  using C8 = Cfg8<WRN, MB, MB1>;
+  constexpr int WCN = C8::WCN, QR = C8::QR, WTR = C8::WTR, BN8 = C8::BN, BUF8 = C8::BUF, BOFF8 = C8::BOFF;
+  constexpr int WV = C8::WV, BMV = C8::BMV;
+  constexpr int PA = C8::PA, PB = C8::PB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int t = threadIdx.x, lane = t & 63, wid = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wid >> 2, wc = wid & 3;
+  const int wr = wid / WCN, wc = wid % WCN;
+  const int grp = wid >> 2;  // waves 0-3 / 4-7 sit on the same four SIMDs: the two ping-pong groups
   int bid = blockIdx.x;
   {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -58,18 +91,24 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   // ---- per-thread DMA rows: quarter tile A[mi] = tile rows {i*128 + mi*64 + [0,64)}, i = 0,1 (the rows both wave rows
   // read in the phases of M-half mi); B[ni] = tile columns {g*64 + ni*32 + [0,32)}, g = 0..3.  A quarter is 16 pieces of
   // 8 rows x 128 B = 1 KiB (one wave-instruction each); wave `wid` moves pieces wid and wid + 8.
-  int a_off[2][2];
-  unsigned a_msk[2][2];
-  unsigned b_off[2][2];
+  int a_off[2][PA];
+  unsigned a_msk[2][PA];
+  unsigned b_off[2][PB];
+  auto a_piece_row = [&](int mi, int i) {  // first tile row of A piece (wid + 8 i) of quarter mi
+    const int q = (wid + 8 * i) * 8;       // row inside the quarter's row list, QR rows per wave row
+    return (q / QR) * WTR + mi * QR + (q % QR);
+  };
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = i * 128 + mi * 64 + wid * 8 + l8;
+    for (int i = 0; i < PA; ++i) {
+      const int row = a_piece_row(mi, i) + l8;   // LDS image row
       const int cc = (lane & 7) ^ ((row >> 1) & 7);
+      const int wrow = row / WTR, rel = row % WTR;  // wave row, row inside the wave tile
       bool valid;
       int nb, oh0, ow0;
-      decode_pixel<TR>(tile_m * BM8 + row, p.M, p.fd_howo, p.fd_wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
+      decode_pixel<TR>(rel < WV ? tile_m * BMV + wrow * WV + rel : p.M, p.M, p.fd_howo, p.fd_wo, HW, p.stride, p.pad, valid, nb,
+                       oh0, ow0);
       a_off[mi][i] = ((nb + oh0 * p.W + ow0) * p.C + cc * 8) * 2;
       unsigned m = 0;
       int ti = 0;
@@ -83,7 +122,7 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PB; ++i) {
       const int g = wid + 8 * i;
       const int brow = (g >> 2) * 64 + ni * 32 + (g & 3) * 8 + l8;
       const int cc = (lane & 7) ^ ((brow >> 1) & 7);
@@ -116,10 +155,9 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   auto dma_A = [&](int buf, int mi) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PA; ++i) {
       const unsigned voff = ((a_msk[mi][i] >> sh) & 1u) ? (unsigned)(a_off[mi][i] + dby) : XR8_OOR;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + buf * BUF8 + (i * 128 + mi * 64 + wid * 8) * 128), 16, voff,
-                                               0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + buf * BUF8 + a_piece_row(mi, i) * 128), 16, voff, 0, 0, 0);
     }
 #else
     (void)buf; (void)mi;
@@ -128,7 +166,7 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   auto dma_B = [&](int buf, int ni) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < PB; ++i) {
       const int g = wid + 8 * i;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rsB, (lds_ptr_t)(smem + buf * BUF8 + BOFF8 + ((g >> 2) * 64 + ni * 32 + (g & 3) * 8) * 128), 16, b_off[ni][i], wk2, 0, 0);
@@ -145,20 +183,20 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   unsigned rd[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) rd[ks] = (unsigned)(lr * 128) + (((unsigned)(ks * 4 + lq) ^ swz) << 4);
-  const unsigned ldsA = lds0 + (unsigned)(wr * 128 * 128), ldsB = lds0 + (unsigned)(BOFF8 + wc * 64 * 128);
+  const unsigned ldsA = lds0 + (unsigned)(wr * WTR * 128), ldsB = lds0 + (unsigned)(BOFF8 + wc * 64 * 128);
 
-  bf16x8_t fa[4][2], fb[2][2];
-  f32x4_t acc[2][4][4];  // [M-half][16-row block][16-col block]: lane holds pixel l&15, channels 4*(l>>4)..+3
+  bf16x8_t fa[MB][2], fb[2][2];
+  f32x4_t acc[2][MB][4];  // [M-half][16-row block][16-col block]: lane holds pixel l&15, channels 4*(l>>4)..+3
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < MB; ++b)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][b][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 #define XR8_RD_A(buf, mi)                                                                        \
-  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
-      fa[mb][ks] = lds_read16((unsigned)((buf) * BUF8) + ldsA + (unsigned)(((mi) * 64 + mb * 16) * 128) + rd[ks]);
+  _Pragma("unroll") for (int mb = 0; mb < ((mi) ? MB1 : MB); ++mb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+      fa[mb][ks] = lds_read16((unsigned)((buf) * BUF8) + ldsA + (unsigned)(((mi) * QR + mb * 16) * 128) + rd[ks]);
 #define XR8_RD_B(buf, ni)                                                                        \
   _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
       fb[nb][ks] = lds_read16((unsigned)((buf) * BUF8) + ldsB + (unsigned)(((ni) * 32 + nb * 16) * 128) + rd[ks]);
@@ -166,7 +204,7 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
   __builtin_amdgcn_sched_barrier(0);                                                                          \
   __builtin_amdgcn_s_setprio(1);                                                                              \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mb = 0; mb < 4; ++mb)           \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mb = 0; mb < ((mi) ? MB1 : MB); ++mb) \
       _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc[mi][mb][(ni) * 2 + nb] =                           \
           __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nb][ks], fa[mb][ks], acc[mi][mb][(ni) * 2 + nb], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                              \
@@ -183,9 +221,9 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   dma_B(0, 0);
   dma_B(0, 1);
   dma_A(0, 1);
-  XR8_VMCNT(2);
+  vmcnt_le<PA>();
   XR8_BAR();
-  if (wr == 1) { XR8_BAR(); }  // wave row 1 runs one barrier behind wave row 0
+  if (grp == 1) { XR8_BAR(); }  // group 1 runs one barrier behind group 0
 
   for (int kk = 0; kk < nk; ++kk) {
     const int buf = kk & 1, nbuf = buf ^ 1;
@@ -205,9 +243,9 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
     XR8_RD_B(buf, 1);
     if (nxt) {
       dma_B(nbuf, 0);
-      XR8_VMCNT(4);
+      vmcnt_le<PA + PB>();
     } else {
-      XR8_VMCNT(0);
+      vmcnt_le<0>();
     }
     XR8_BAR();
     XR8_MMA(0, 1);
@@ -222,16 +260,16 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
     XR8_RD_B(buf, 0);
     if (nxt) {
       dma_A(nbuf, 1);
-      XR8_VMCNT(2);
+      vmcnt_le<PA>();
     }
     XR8_BAR();
     XR8_MMA(1, 0);
     XR8_BAR();
   }
-  if (wr == 0) { XR8_BAR(); }  // re-align the two wave rows: every operand read is retired, LDS is free for the epilogue
+  if (grp == 0) { XR8_BAR(); }  // re-align the two groups: every operand read is retired, LDS is free for the epilogue
 
   // ---- epilogue: accumulators (+bias) -> wave-private [128 pixels][64 channels] bf16 image (same chunk swizzle) -> rows
-  unsigned char* img = smem + wid * (128 * 128);
+  unsigned char* img = smem + wid * C8::IMG;
   {
     float bv[4][4];
 #pragma unroll
@@ -244,10 +282,10 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < (mi ? MB1 : MB); ++mb)
 #pragma unroll
         for (int nn = 0; nn < 4; ++nn) {
-          const int row = mi * 64 + mb * 16 + lr;
+          const int row = mi * QR + mb * 16 + lr;
           const int chunk = nn * 2 + (lq >> 1);
           const f32x4_t v = acc[mi][mb][nn];
           uint2 pk;
@@ -268,9 +306,9 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   for (int e = 0; e < 8; ++e) dal[e] = 0.f, alv[e] = 0.f;
   if (ep && ncol < p.K) ld8(p.ep_alpha + ncol, alv);
 #pragma unroll 4
-  for (int it = 0; it < 16; ++it) {
+  for (int it = 0; it < WV / 8; ++it) {
     const int row = it * 8 + l8;
-    const int m = tile_m * BM8 + wr * 128 + row;
+    const int m = tile_m * BMV + wr * WV + row;
     if (m >= p.M || ncol >= Kw) continue;
     const bf16_t* sp = reinterpret_cast<const bf16_t*>(img + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
     bf16_t* dp = out + (size_t)m * p.ldo + ncol;
@@ -289,54 +327,103 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
       *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
     }
   }
-  if (ep) {  // lanes sharing a chunk column are 8 apart
+  if (ep) {
+    // dalpha: fold lanes (same chunk column = 8 apart), then the wave rows through LDS, then ONE atomic per column and
+    // workgroup issued as full 64-lane instructions -- per-wave atomics (8 x 64 per tile onto the same few cache lines of
+    // dalpha, from every CU at once) serialise at the memory side and cost more than the whole main loop
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float v = dal[e];
       v += __shfl_xor(v, 8, 64);
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
-      if (lane < 8 && ncol + e < p.K) atomicAdd(p.ep_dalpha + ncol + e, v);
+      dal[e] = v;
+    }
+    __syncthreads();  // every wave is done with its epilogue image
+    float* red = reinterpret_cast<float*>(smem);
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wid * 64 + lane * 8 + e] = dal[e];
+    }
+    __syncthreads();
+    for (int c = t; c < BN8; c += NT8) {
+      const int cwc = c >> 6, cc = c & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < WRN; ++r) sum += red[(r * WCN + cwc) * 64 + cc];
+      if (n0 + c < p.K) atomicAdd(p.ep_dalpha + n0 + c, sum);
     }
   }
 }
 
 }  // namespace
 
-bool xr_igemm8_eligible(const IgemmP& p, int dtype, int transposed) {
-  if (g_tune[7] == 0 || dtype != XR_BF16) return false;
-  if (p.ws != nullptr || p.K % 8 != 0 || p.C % 64 != 0 || p.Kg != p.R * p.S * p.C || p.R * p.S > 32) return false;
-  if (transposed && p.stride != 1) return false;
+// tile configuration for a problem: 0 none, 1 = 256x256, 2 = 256x128, 3 = 128x256, 4 = 224x256, 5 = 512x128, 6 = 448x128
+static int igemm8_config(const IgemmP& p, int dtype, int transposed) {
+  const int knob = g_tune[7];
+  if (knob == 0 || dtype != XR_BF16) return 0;
+  if (p.ws != nullptr || p.K % 8 != 0 || p.C % 64 != 0 || p.Kg != p.R * p.S * p.C || p.R * p.S > 32) return 0;
+  if (transposed && p.stride != 1) return 0;
   const long long in_bytes = (long long)p.N * p.H * p.W * p.C * 2, w_bytes = (long long)p.K * p.Kg * 2;
-  if (in_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return false;
-  if (g_tune[7] == 2) return true;  // forced (tests / tuning)
-  // auto: full-width column tiles and enough row tiles to occupy most of the 256 CUs
-  const long long tiles = (long long)cdiv(p.M, BM8) * cdiv(p.K, BN8);
-  return p.K % BN8 == 0 && tiles >= 160;
+  if (in_bytes >= (1ll << 31) || w_bytes >= (1ll << 31)) return 0;
+  if (knob >= 3 && knob <= 8) return knob - 2;  // forced configuration (tests / tuning)
+  // auto (knob 1; knob 2 drops the occupancy thresholds).  One workgroup per CU: time ~ rounds x rows per tile.  Only the
+  // 128x64-per-wave configurations beat the 4-wave kernel (measured: tools/conv_bench.py), so 256x128 / 128x256 stay manual.
+  const bool force = knob == 2;
+  if (p.Kg < 8 * 64 && !force) return 0;  // short reductions (1x1 shortcuts) cannot amortise the 64-128 KiB prologue
+  if (p.K % 256 == 0) {
+    const long long t256 = (long long)cdiv(p.M, 256) * (p.K / 256), t224 = (long long)cdiv(p.M, 224) * (p.K / 256);
+    if (t256 < 160 && !force) return 0;
+    if (knob == 10) return 1;
+    return cdiv(t224, 256) * 224 < cdiv(t256, 256) * 256 ? 4 : 1;
+  }
+  if (p.K % 128 == 0 && knob != 9 && knob != 10) {
+    const long long t512 = (long long)cdiv(p.M, 512) * (p.K / 128), t448 = (long long)cdiv(p.M, 448) * (p.K / 128);
+    if (t512 < 160 && !force) return 0;
+    return cdiv(t448, 256) * 448 < cdiv(t512, 256) * 512 ? 6 : 5;
+  }
+  return 0;
 }
 
-int xr_igemm8_launch(IgemmP& p, int transposed, hipStream_t st) {
-  p.tiles_n = cdiv((p.K + 7) / 8 * 8, BN8);
-  const int tiles_m = cdiv(p.M, BM8);
-  p.cls = 0; p.tpc = 0; p.Mc = 0; p.ksplit = 0;
-  p.fd_howo = make_fd((unsigned)(p.Ho * p.Wo));
-  p.fd_wo = make_fd((unsigned)p.Wo);
+bool xr_igemm8_eligible(const IgemmP& p, int dtype, int transposed) { return igemm8_config(p, dtype, transposed) != 0; }
+
+template <bool TR, int WRN, int MB, int MB1 = MB>
+static int igemm8_launch_cfg(IgemmP& p, hipStream_t st) {
+  using C8 = Cfg8<WRN, MB, MB1>;
+  p.tiles_n = cdiv((p.K + 7) / 8 * 8, C8::BN);
+  const int tiles_m = cdiv(p.M, C8::BMV);
   p.fd_tn = make_fd((unsigned)p.tiles_n);
-  p.in_bytes = (unsigned)((long long)p.N * p.H * p.W * p.C * 2);
-  p.w_bytes = (unsigned)((long long)p.K * p.Kg * 2);
-  constexpr int smem = 2 * BUF8;
-  static bool attr_done[2] = {false, false};
-  const void* fn = transposed ? reinterpret_cast<const void*>(igemm8_kernel<true>) : reinterpret_cast<const void*>(igemm8_kernel<false>);
-  if (!attr_done[transposed ? 1 : 0]) {
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  constexpr int smem = 2 * C8::BUF;
+  static bool attr_done = false;
+  auto kern = igemm8_kernel<TR, WRN, MB, MB1>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       xr_set_error("xr_conv_igemm(8-wave): hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e));
       return XR_E_LAUNCH;
     }
-    attr_done[transposed ? 1 : 0] = true;
+    attr_done = true;
   }
-  if (transposed) hipLaunchKernelGGL(igemm8_kernel<true>, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT8), smem, st, p);
-  else hipLaunchKernelGGL(igemm8_kernel<false>, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT8), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT8), smem, st, p);
   XR_CHECK_LAUNCH("xr_conv_igemm(8-wave)");
   return XR_OK;
+}
+
+int xr_igemm8_launch(IgemmP& p, int transposed, hipStream_t st) {
+  const int cfg = igemm8_config(p, XR_BF16, transposed);
+  p.cls = 0; p.tpc = 0; p.Mc = 0; p.ksplit = 0;
+  p.fd_howo = make_fd((unsigned)(p.Ho * p.Wo));
+  p.fd_wo = make_fd((unsigned)p.Wo);
+  p.in_bytes = (unsigned)((long long)p.N * p.H * p.W * p.C * 2);
+  p.w_bytes = (unsigned)((long long)p.K * p.Kg * 2);
+  switch (cfg) {
+    case 1: return transposed ? igemm8_launch_cfg<true, 2, 4>(p, st) : igemm8_launch_cfg<false, 2, 4>(p, st);
+    case 2: return transposed ? igemm8_launch_cfg<true, 4, 2>(p, st) : igemm8_launch_cfg<false, 4, 2>(p, st);
+    case 3: return transposed ? igemm8_launch_cfg<true, 2, 2>(p, st) : igemm8_launch_cfg<false, 2, 2>(p, st);
+    case 4: return transposed ? igemm8_launch_cfg<true, 2, 4, 3>(p, st) : igemm8_launch_cfg<false, 2, 4, 3>(p, st);
+    case 5: return transposed ? igemm8_launch_cfg<true, 4, 4>(p, st) : igemm8_launch_cfg<false, 4, 4>(p, st);
+    case 6: return transposed ? igemm8_launch_cfg<true, 4, 4, 3>(p, st) : igemm8_launch_cfg<false, 4, 4, 3>(p, st);
+  }
+  xr_set_error("xr_conv_igemm(8-wave): problem not eligible");
+  return XR_E_INVALID;
 }

@@ -67,6 +67,9 @@ class _Lib:
             fn.restype = res
             fn.argtypes = args
         self._dll = dll
+        for kv in filter(None, os.environ.get("XR_TUNE", "").split(",")):  # e.g. XR_TUNE="7=0,6=18": kernel tuning knobs
+            k, v = kv.split("=")
+            dll.xr_tune(int(k), int(v))
         return dll
 
     def __getattr__(self, name):

@@ -91,8 +91,9 @@ CONV8_CASES = [
 ]
 
 
+@pytest.mark.parametrize("cfg", [3, 4, 5, 6, 7, 8])   # xr_tune knob 7: force tile configuration 256x256, 256x128, 128x256, 224x256, 512x128, 448x128
 @pytest.mark.parametrize("case", CONV8_CASES)
-def test_conv2d_8wave_kernel(case):
+def test_conv2d_8wave_kernel(case, cfg):
     """xr_conv8.hip (8-wave ping-pong tile) against the fp32 CPU conv: forward, input gradient (same kernel, transposed
     gather) and -- unchanged kernel, sanity only -- the weight gradient."""
     from xrface import ops
@@ -107,7 +108,7 @@ def test_conv2d_8wave_kernel(case):
     y_ref = F.conv2d(xr, wr, br, stride, pad)
     gy = rnd(f"c8g{case}", *y_ref.shape)
     y_ref.backward(gy)
-    lib.xr_tune(7, 2)
+    lib.xr_tune(7, cfg)
     try:
         xg = x.to(DEV).requires_grad_(True)
         wg = w.to(DEV).requires_grad_(True)
@@ -144,7 +145,7 @@ def test_conv2d_8wave_prelu_backward_epilogue():
     g = rnd("c8pg", *out_ref.shape)
     out_ref.backward(g)
     res = {}
-    for knob in (2, 0):
+    for knob in (3, 4, 5, 6, 7, 8, 0):
         lib.xr_tune(7, knob)
         try:
             yg, ag, wg = y0.to(DEV).requires_grad_(True), al.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
@@ -157,7 +158,8 @@ def test_conv2d_8wave_prelu_backward_epilogue():
         assert rel(out, out_ref) < TOL[torch.bfloat16]
         assert rel(yg.grad, yr.grad) < TOL[torch.bfloat16]
         assert rel(ag.grad, ar.grad) < 4e-2
-    assert rel(res[2][1], res[0][1]) < 1e-2
+    for knob in (3, 4, 5, 6, 7, 8):
+        assert rel(res[knob][1], res[0][1]) < 1e-2
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
