@@ -542,7 +542,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void i
     for (int c = t; c < BN; c += NT) {
       float sum = 0.f;
       for (int r = 0; r < NT / CPR; ++r) sum += red[r * BN + c];
-      if (n0 + c < p.K) atomicAdd(p.ep_dalpha + n0 + c, sum);
+      if (n0 + c < p.K) atomicAdd(p.ep_dalpha + (size_t)(tile_m % p.ep_spread) * p.K + n0 + c, sum);
     }
   }
 }
@@ -1268,7 +1268,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
 extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                              int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
-                             const float* ep_alpha, float* ep_dalpha, void* stream) {
+                             const float* ep_alpha, float* ep_dalpha, int ep_spread, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
   XR_CHECK_ARG(ep_src == nullptr || (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
                "xr_conv_igemm: fused PReLU-backward epilogue needs alpha, dalpha, K %% 8 == 0, no bias, no split-K");
@@ -1290,7 +1290,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, g_tune[4]};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, ep_spread > 0 ? ep_spread : 1, g_tune[4]};
   hipStream_t st = (hipStream_t)stream;
   if (xr_igemm8_eligible(p, dtype, transposed)) return xr_igemm8_launch(p, transposed, st);
   const bool wide = K > 64 && g_tune[3] == 0;

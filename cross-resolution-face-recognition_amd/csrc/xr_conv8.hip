@@ -351,7 +351,7 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
       float sum = 0.f;
 #pragma unroll
       for (int r = 0; r < WRN; ++r) sum += red[(r * WCN + cwc) * 64 + cc];
-      if (n0 + c < p.K) atomicAdd(p.ep_dalpha + n0 + c, sum);
+      if (n0 + c < p.K) atomicAdd(p.ep_dalpha + (size_t)(tile_m % p.ep_spread) * p.K + n0 + c, sum);
     }
   }
 }

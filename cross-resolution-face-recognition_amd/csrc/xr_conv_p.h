@@ -40,7 +40,8 @@ struct IgemmP {
   // dalpha[c] += sum acc * y * [y <= 0];  ep_src = y laid out like `out`
   const void* ep_src;
   const float* ep_alpha;
-  float* ep_dalpha;
+  float* ep_dalpha;   // [ep_spread][K]; row tile i adds into row i % ep_spread (spreads the hot atomic lines)
+  int ep_spread;
   int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
 };
 

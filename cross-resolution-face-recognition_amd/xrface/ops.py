@@ -14,7 +14,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512"))}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32}
 
 
 def set_compute_dtype(dtype):
@@ -254,7 +254,7 @@ class _Conv2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, None, None, None, stream())
+                          kg, Kp, None, 0, None, None, None, 1, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -275,7 +275,7 @@ class _Conv2d(Function):
             pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, None, 0, None, None, None, stream())
+                              kg, Cp, None, 0, None, None, None, 1, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
@@ -302,7 +302,7 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
-                          kg, Kp, None, 0, None, None, None, stream())
+                          kg, Kp, None, 0, None, None, None, 1, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -324,7 +324,7 @@ class _ConvTranspose2d(Function):
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
-                              kg, Cp, None, 0, None, None, None, stream())
+                              kg, Cp, None, 0, None, None, None, 1, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
             kg = kg_of(R * S, Cp)
@@ -354,11 +354,11 @@ class _LinearNHWC(Function):
         split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1,
                               stream())
             lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1,
                               stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -380,7 +380,7 @@ class _LinearNHWC(Function):
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
-                              HW * C, None, 0, None, None, None, stream())
+                              HW * C, None, 0, None, None, None, 1, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
             dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
@@ -407,7 +407,7 @@ class _PreluConv2d(Function):
         Kp = r8(K)
         y2 = torch.empty((N, Ho, Wo, Kp), dtype=y1.dtype, device=y1.device)
         lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
-                          None, None, None, stream())
+                          None, None, None, 1, stream())
         ctx.save_for_backward(y1, p1, w, al)
         ctx.geom = (stride, pad)
         ctx.alpha_ref = alpha
@@ -428,11 +428,20 @@ class _PreluConv2d(Function):
         dy1 = dalpha = dw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             t_a = _direct(alpha)
-            dal = t_a if t_a is not None else zeros_f32((C,), dev)
+            # dalpha partial sums are spread over `sp` rows (row tile i -> row i % sp) and folded afterwards: thousands of
+            # tiles adding into the same C floats serialise at the memory side (measured: +60 us on a 100 us kernel)
+            sp = _cfg["dalpha_spread"] if N * H * W >= 32 * 1024 else 1
+            if sp > 1:
+                dal_s = zeros_f32((sp, C), dev)
+                dal = t_a if t_a is not None else torch.empty((C,), dtype=torch.float32, device=dev)
+            else:
+                dal_s = dal = t_a if t_a is not None else zeros_f32((C,), dev)
             pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
             lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
-                              0, ptr(y1), ptr(al), ptr(dal), stream())
+                              0, ptr(y1), ptr(al), ptr(dal_s), sp, stream())
+            if sp > 1:
+                lib.xr_reduce_groups(ptr(dal_s), ptr(dal), 1, sp, C, 1 if t_a is not None else 0, stream())
             if t_a is not None:
                 _direct_done(alpha)
             else:
