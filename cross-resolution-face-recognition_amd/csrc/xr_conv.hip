@@ -13,7 +13,9 @@
 // Replaces the ATen conv calls issued by /root/reference model/FSRnet.py:79,85,110,312,318,345,351,384,391,
 // 392,432,436,439; SUPER_RESOLUTION/model/model_irse.py:56-60,140,147; model/resnet.py:9-16,158,170.
 #include "xr_conv_p.h"
+#include <string.h>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -93,7 +95,7 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 // VGPRs nor ds_write issue slots (the LDS write port is ~80 B/clk on gfx950) are spent on staging.  The LDS image is
 // lane-linear, so the XOR swizzle is applied to the SOURCE chunk each lane fetches.
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT>
-__global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void igemm_kernel(IgemmP p) {
+__global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2 : 4) : 1) void igemm_kernel(IgemmP p) {
   const bool g_prio = p.prio != 0;
   constexpr int NBUF = DMA ? DMA : 1;
   static_assert(DMA == 0 || (FAST && MODE == 0), "DMA staging needs the FAST bf16 path");
@@ -413,11 +415,14 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? 4 : 1) void i
     int buf = 0;
     for (int kk = kbeg; kk < nk; ++kk) {
       if (kk + 1 < nk) {
-        if constexpr (RA + RB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (RA + RB == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if constexpr (RA + RB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if constexpr (RA + RB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if constexpr (RA + RB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if constexpr (RA + RB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        static_assert(RA + RB == 8 || RA + RB == 6 || RA + RB == 4 || RA + RB == 3, "unexpected DMA instruction count");
+        static_assert(RA + RB == 10 || RA + RB == 5 || RA + RB == 8 || RA + RB == 6 || RA + RB == 4 || RA + RB == 3,
+                      "unexpected DMA instruction count");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -1044,10 +1049,9 @@ __global__ void unpack_wgrad4_kernel(const float* __restrict__ packed, float* __
 // ---- LDS-tiled layout converters for the two conv-shaped cases (both sides of the transpose stay coalesced) ----------
 // (1) parameter [A][B][taps] (taps contiguous: Conv2d [K][C][R][S], Linear [K][C*HW])  <->  pack [A][tap][Bp]
 //     block = (row a, 64 consecutive b): 64*taps contiguous floats on the parameter side, 64-wide rows on the pack side
-__global__ __launch_bounds__(256) void pack_fwdform_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
-                                                           int taps, int B, int Bp, int Kg, int64_t plane) {
-  extern __shared__ float tile[];
-  const int a = blockIdx.y, b0 = blockIdx.x * 64, t = threadIdx.x;
+__device__ __forceinline__ void pack_fwdform_body(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes, int taps,
+                                                  int B, int Bp, int Kg, int64_t plane, int bx, int by, float* tile) {
+  const int a = by, b0 = bx * 64, t = threadIdx.x;
   const int nb = (B - b0) < 64 ? (B - b0) : 64;
   const float* sp = src + ((int64_t)a * B + b0) * taps;
   for (int j = t; j < nb * taps; j += 256) tile[j] = sp[j];
@@ -1064,9 +1068,14 @@ __global__ __launch_bounds__(256) void pack_fwdform_kernel(const float* __restri
       v -= bf2f(h);
     }
   }
-  if (blockIdx.x == 0)
+  if (bx == 0)
     for (int j = taps * Bp + t; j < Kg; j += 256)
       for (int q = 0; q < nplanes; ++q) dst[(int64_t)q * plane + (int64_t)a * Kg + j] = 0;
+}
+__global__ __launch_bounds__(256) void pack_fwdform_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
+                                                           int taps, int B, int Bp, int Kg, int64_t plane) {
+  extern __shared__ float tile[];
+  pack_fwdform_body(src, dst, nplanes, taps, B, Bp, Kg, plane, blockIdx.x, blockIdx.y, tile);
 }
 
 __global__ __launch_bounds__(256) void unpack_fwdform_kernel(const float* __restrict__ packed, float* __restrict__ dst, int taps,
@@ -1090,10 +1099,10 @@ __global__ __launch_bounds__(256) void unpack_fwdform_kernel(const float* __rest
 
 // (2) parameter [B][A][taps] -> pack [A][tap][Bp]  (the input-gradient pack of a Conv2d: rows = input channel a,
 //     columns = (tap, output channel b)): block = (4 rows a, 64 columns b)
-__global__ __launch_bounds__(256) void pack_dgradform_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
-                                                             int taps, int A, int B, int Bp, int Kg, int64_t plane) {
-  extern __shared__ float tile[];  // [64][4*taps + 1]
-  const int a0 = blockIdx.y * 4, b0 = blockIdx.x * 64, t = threadIdx.x;
+__device__ __forceinline__ void pack_dgradform_body(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes, int taps,
+                                                    int A, int B, int Bp, int Kg, int64_t plane, int bx, int by, float* tile) {
+  // tile: [64][4*taps + 1]
+  const int a0 = by * 4, b0 = bx * 64, t = threadIdx.x;
   const int na = (A - a0) < 4 ? (A - a0) : 4, nb = (B - b0) < 64 ? (B - b0) : 64;
   const int rowlen = na * taps, pitch = 4 * taps + 1;
   for (int e = t; e < 64 * rowlen; e += 256) {
@@ -1114,10 +1123,58 @@ __global__ __launch_bounds__(256) void pack_dgradform_kernel(const float* __rest
       v -= bf2f(h);
     }
   }
-  if (blockIdx.x == 0)
+  if (bx == 0)
     for (int al = 0; al < na; ++al)
       for (int j = taps * Bp + t; j < Kg; j += 256)
         for (int q = 0; q < nplanes; ++q) dst[(int64_t)q * plane + (int64_t)(a0 + al) * Kg + j] = 0;
+}
+__global__ __launch_bounds__(256) void pack_dgradform_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int nplanes,
+                                                             int taps, int A, int B, int Bp, int Kg, int64_t plane) {
+  extern __shared__ float tile[];
+  pack_dgradform_body(src, dst, nplanes, taps, A, B, Bp, Kg, plane, blockIdx.x, blockIdx.y, tile);
+}
+
+// ---- batched pack: one launch refreshes every registered parameter pack (xr_pack_plan / xr_pack_run) ------------------
+struct PackEntry {          // 128 bytes, device table
+  const float* src;
+  bf16_t* dst;
+  int64_t sa1, sa2, st, sb, total;
+  int nplanes, A1, A2, taps, B, Bp, Kg, form;   // form: 0 generic, 1 fwd-form, 2 dgrad-form
+  int blk0, nblk, gx, pad_;
+  int64_t pad2_[3];
+};
+static_assert(sizeof(PackEntry) == 128, "PackEntry layout");
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __restrict__ table, int n) {
+  extern __shared__ float tile[];
+  int lo = 0, hi = n - 1;  // last entry with blk0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackEntry e = table[lo];
+  const int lb = blockIdx.x - e.blk0;
+  if (e.form == 1) {
+    pack_fwdform_body(e.src, e.dst, e.nplanes, e.taps, e.B, e.Bp, e.Kg, e.total, lb % e.gx, lb / e.gx, tile);
+  } else if (e.form == 2) {
+    pack_dgradform_body(e.src, e.dst, e.nplanes, e.taps, e.A1, e.B, e.Bp, e.Kg, e.total, lb % e.gx, lb / e.gx, tile);
+  } else {
+    for (int64_t i = lb * 256ll + threadIdx.x; i < e.total; i += e.nblk * 256ll) {
+      const int64_t a = i / e.Kg;
+      const int j = (int)(i - a * e.Kg);
+      const int tp = j / e.Bp, b = j - tp * e.Bp;
+      float v = 0.f;
+      if (tp < e.taps && b < e.B) {
+        const int64_t a1 = a / e.A2, a2 = a - a1 * e.A2;
+        v = e.src[a1 * e.sa1 + a2 * e.sa2 + tp * e.st + b * e.sb];
+      }
+      for (int q = 0; q < e.nplanes; ++q) {
+        const bf16_t h = f2bf(v);
+        e.dst[(int64_t)q * e.total + i] = h;
+        v -= bf2f(h);
+      }
+    }
+  }
 }
 
 // (3) Linear input-gradient pack: dst[(p*C + c)][k] = W[k][c*HW + p]  (rows in NHWC-flatten order, k contiguous).
@@ -1166,6 +1223,58 @@ __global__ void bias_cast_kernel(const float* __restrict__ ws, const float* __re
 }
 
 }  // namespace
+
+extern "C" int xr_pack_plan(const int64_t* entries, int n, void* table_dev, int* smem_out, void* stream) {
+  XR_CHECK_ARG(entries && table_dev && smem_out && n > 0, "xr_pack_plan: null pointer or empty plan");
+  std::vector<PackEntry> tab((size_t)n);
+  int blk = 0, smem = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t* f = entries + (size_t)i * 14;
+    PackEntry& e = tab[(size_t)i];
+    memset(&e, 0, sizeof(e));
+    e.src = reinterpret_cast<const float*>((uintptr_t)f[0]);
+    e.dst = reinterpret_cast<bf16_t*>((uintptr_t)f[1]);
+    e.nplanes = (int)f[2]; e.A1 = (int)f[3]; e.A2 = (int)f[4]; e.taps = (int)f[5]; e.B = (int)f[6]; e.Bp = (int)f[7]; e.Kg = (int)f[8];
+    e.sa1 = f[9]; e.sa2 = f[10]; e.st = f[11]; e.sb = f[12];
+    XR_CHECK_ARG(e.src && e.dst && (e.nplanes == 1 || e.nplanes == 3) && e.A1 > 0 && e.A2 > 0 && e.taps > 0 && e.B > 0 &&
+                     e.Bp >= e.B && e.Bp % 8 == 0 && e.Kg % 64 == 0 && e.Kg >= e.taps * e.Bp,
+                 "xr_pack_plan: bad entry %d", i);
+    e.total = (int64_t)e.A1 * e.A2 * e.Kg;
+    int need = 0;
+    e.form = 0;
+    if (e.A2 == 1 && e.st == 1 && e.taps <= 64) {
+      if (e.sb == e.taps && e.sa1 == (int64_t)e.B * e.taps) {
+        e.form = 1; e.gx = cdiv(e.Bp, 64); e.nblk = e.gx * e.A1; need = 64 * e.taps * 4;
+      } else if (e.sa1 == e.taps && e.sb == (int64_t)e.A1 * e.taps) {
+        e.form = 2; e.gx = cdiv(e.Bp, 64); e.nblk = e.gx * cdiv(e.A1, 4); need = 64 * (4 * e.taps + 1) * 4;
+      }
+    }
+    if (e.form != 0 && need > 48 * 1024) { e.form = 0; need = 0; }
+    if (e.form == 0) {
+      e.gx = 1;
+      e.nblk = (int)((e.total + 256 * 16 - 1) / (256 * 16));
+      if (e.nblk > 1024) e.nblk = 1024;
+    }
+    e.blk0 = blk;
+    blk += e.nblk;
+    if (need > smem) smem = need;
+  }
+  if (hipMemcpyAsync(table_dev, tab.data(), sizeof(PackEntry) * (size_t)n, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {  // the host vector dies at return
+    xr_set_error("xr_pack_plan: table upload failed");
+    return XR_E_LAUNCH;
+  }
+  *smem_out = smem;
+  return blk;
+}
+
+extern "C" int xr_pack_run(const void* table_dev, int n, int blocks, int smem, void* stream) {
+  XR_CHECK_ARG(table_dev && n > 0 && blocks > 0 && smem >= 0 && smem <= 48 * 1024, "xr_pack_run: bad arguments");
+  hipLaunchKernelGGL(pack_batch_kernel, dim3((unsigned)blocks), dim3(256), (size_t)smem, (hipStream_t)stream,
+                     reinterpret_cast<const PackEntry*>(table_dev), n);
+  XR_CHECK_LAUNCH("xr_pack_run");
+  return XR_OK;
+}
 
 extern "C" int xr_tune(int knob, int value) {
   XR_CHECK_ARG(knob >= 0 && knob < 8, "xr_tune: knob out of range");
@@ -1296,6 +1405,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
   const bool wide = K > 64 && g_tune[3] == 0;
   if (dtype == XR_BF16) {
     if (wide) return transposed ? launch_igemm<0, 128, 128, 2, true>(p, st) : launch_igemm<0, 128, 128, 2, false>(p, st);
+    if (g_tune[3] == 2) return transposed ? launch_igemm<0, 256, 64, 4, true>(p, st) : launch_igemm<0, 256, 64, 4, false>(p, st);
     return transposed ? launch_igemm<0, 128, 64, 4, true>(p, st) : launch_igemm<0, 128, 64, 4, false>(p, st);
   }
   if (wide) return transposed ? launch_igemm<1, 128, 128, 2, true>(p, st) : launch_igemm<1, 128, 128, 2, false>(p, st);

@@ -15,6 +15,7 @@ from torch.nn import Module, Sequential
 from .. import nn as xnn
 from .. import ops
 from ..ops import enter, leave, leave2d
+from ..nn import batched_bn_counters
 
 Conv2d, BatchNorm1d, BatchNorm2d, PReLU, ReLU, Dropout, MaxPool2d, Linear = (
     xnn.Conv2d, xnn.BatchNorm1d, xnn.BatchNorm2d, xnn.PReLU, xnn.ReLU, xnn.Dropout, xnn.MaxPool2d, xnn.Linear)
@@ -156,6 +157,10 @@ class Backbone(Module):
         return ol[4].f(ol[3].f(y))
 
     def f(self, buf, taps=()):
+        with batched_bn_counters(self):
+            return self._f(buf, taps)
+
+    def _f(self, buf, taps=()):
         y = self.f_input(buf)
         tapped = []
         for i, blk in enumerate(self.body):

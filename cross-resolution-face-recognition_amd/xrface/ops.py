@@ -7,6 +7,9 @@ Every op fails loudly when the HIP library is unavailable -- there is no CPU pat
 """
 from __future__ import annotations
 
+import ctypes
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -14,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1}
 
 
 def set_compute_dtype(dtype):
@@ -123,9 +126,72 @@ def _emit_small(p, val):
 _pack_epoch = [0]
 
 
-def invalidate_weight_cache():
-    """Fused optimizers update parameters through raw pointers (no version bump): they call this."""
-    _pack_epoch[0] += 1
+def invalidate_weight_cache(params=None):
+    """Fused optimizers update parameters through raw pointers (no version bump): they call this, with the parameters
+    they touched (packs of other, e.g. frozen-teacher, parameters stay valid) or without (everything is stale)."""
+    if params is None:
+        _pack_epoch[0] += 1
+    else:
+        for p in params:
+            p.__dict__["_xr_epoch"] = p.__dict__.get("_xr_epoch", 0) + 1
+
+
+def _pack_tag(w):
+    return (w._version, w.data_ptr(), _pack_epoch[0], w.__dict__.get("_xr_epoch", 0), tuple(w.shape))
+
+
+class _PackPlan:
+    """Every (parameter, pack form) seen so far, refreshed by ONE launch (xr_pack_run) when any of them went stale --
+    instead of ~110 per-layer pack launches after each optimizer step.  Pack buffers are persistent: a refresh overwrites
+    them in stream order, after every kernel of the previous step that read them."""
+
+    def __init__(self):
+        self.entries = []     # [weakref(w), key, pk, kg, args]
+        self.index = {}       # (id(w), key) -> entry
+        self.table = None
+        self.meta = None      # (n, blocks, smem)
+        self.ptrs = None      # source pointers the table was built for
+
+    def add(self, w, key, pk, kg, args):
+        e = [weakref.ref(w), key, pk, kg, args]
+        self.entries.append(e)
+        self.index[(id(w), key)] = e
+        self.table = None
+
+    def _build(self, live):
+        import numpy as np
+        ent = np.zeros((len(live), 14), dtype=np.int64)
+        for i, (w, e) in enumerate(live):
+            planes, A1, A2, taps, B, Bp, sa1, sa2, st, sb = e[4]
+            ent[i] = (w.data_ptr(), e[2].data_ptr(), planes, A1, A2, taps, B, Bp, e[3], sa1, sa2, st, sb, 0)
+        self.table = torch.empty(len(live) * 128, dtype=torch.uint8, device=live[0][0].device)
+        smem = ctypes.c_int(0)
+        blocks = lib.xr_pack_plan(ent.ctypes.data, len(live), ptr(self.table), ctypes.addressof(smem), stream())
+        self.meta = (len(live), blocks, smem.value)
+        self.ptrs = [w.data_ptr() for w, _ in live]
+
+    def refresh(self):
+        live = []
+        for e in self.entries:
+            w = e[0]()
+            if w is not None and w.__dict__.get("_xr_pack", {}).get(e[1], (None, None))[1] is e[2] and w.dtype == torch.float32 \
+                    and w.is_contiguous():
+                live.append((w, e))
+        if len(live) != len(self.entries):
+            self.entries = [e for _, e in live]
+            self.index = {(id(w), e[1]): e for w, e in live}
+            self.table = None
+        if not live:
+            return
+        if self.table is None or self.ptrs != [w.data_ptr() for w, _ in live] or self.table.device != live[0][0].device:
+            self._build(live)
+        n, blocks, smem = self.meta
+        lib.xr_pack_run(ptr(self.table), n, blocks, smem, stream())
+        for w, e in live:
+            w.__dict__["_xr_pack"][e[1]] = (_pack_tag(w), e[2], e[3])
+
+
+_pack_plan = _PackPlan()
 
 
 def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
@@ -133,19 +199,28 @@ def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
     (so it dies with it) and is refreshed whenever the parameter's version / storage / epoch changes."""
     cache = w.__dict__.setdefault("_xr_pack", {})
     key = (kind, dtype, Bp)
-    tag = (w._version, w.data_ptr(), _pack_epoch[0], tuple(w.shape))
+    tag = _pack_tag(w)
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
         return hit[1], hit[2]
+    if hit is not None and _cfg["pack_plan"] and (id(w), key) in _pack_plan.index and w.device.type == "cuda":
+        _pack_plan.refresh()      # stale registered pack: refresh ALL registered packs in one launch
+        hit = cache.get(key)
+        if hit is not None and hit[0] == _pack_tag(w):
+            return hit[1], hit[2]
     kg = kg_of(taps, Bp)
     rows = A1 * A2
     planes = 3 if dtype == torch.float32 else 1
     pk = torch.empty((planes, rows, kg), dtype=torch.bfloat16, device=w.device)
     wd = w.detach()
-    if wd.dtype != torch.float32 or not wd.is_contiguous():
+    plain = wd.dtype == torch.float32 and wd.is_contiguous()
+    if not plain:
         wd = wd.float().contiguous()
     lib.xr_pack_weight(ptr(wd), ptr(pk), planes, A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, stream())
     cache[key] = (tag, pk, kg)
+    if plain and _cfg["pack_plan"] and w.device.type == "cuda" and not (taps == 1 and sa1 == 1 and A1 <= 64 and A2 > 1):
+        # (the Linear input-gradient form keeps its own LDS-tiled kernel: its tile does not fit the batch kernel's LDS budget)
+        _pack_plan.add(w, key, pk, kg, (planes, A1, A2, taps, B, Bp, sa1, sa2, st, sb))
     return pk, kg
 
 
@@ -764,8 +839,7 @@ class _BnSeAdd(Function):
 def bn_se_add(y, bn, se, shortcut):
     """bn: an xrface.nn.BatchNorm2d holder, se: a model_irse.SEModule holder."""
     training = bn.training or not bn.track_running_stats
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bn._count()
     mom = 0.1 if bn.momentum is None else bn.momentum
     return _BnSeAdd.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, se.fc1.weight, se.fc2.weight, shortcut, training,
                           mom, bn.eps)

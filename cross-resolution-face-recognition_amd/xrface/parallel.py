@@ -164,7 +164,7 @@ class FusedSGD(_FlatOptimizer):
         lib.xr_sgd_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.mom), self.flat.numel, g["lr"], g["momentum"],
                         g["weight_decay"], ptr(self.mask), int(self._steps == 0), stream())
         self._steps += 1
-        ops.invalidate_weight_cache()
+        ops.invalidate_weight_cache(self.flat.params)
 
 
 class FusedRMSprop(_FlatOptimizer):
@@ -180,7 +180,7 @@ class FusedRMSprop(_FlatOptimizer):
         lib.xr_rmsprop_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.sq), self.flat.numel, g["lr"], g["alpha"],
                             g["eps"], g["weight_decay"], stream())
         self._steps += 1
-        ops.invalidate_weight_cache()
+        ops.invalidate_weight_cache(self.flat.params)
 
 
 class FusedAdam(_FlatOptimizer):
@@ -197,4 +197,4 @@ class FusedAdam(_FlatOptimizer):
         self._steps += 1
         lib.xr_adam_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.m), ptr(self.v), self.flat.numel, g["lr"],
                          g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps, stream())
-        ops.invalidate_weight_cache()
+        ops.invalidate_weight_cache(self.flat.params)

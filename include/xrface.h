@@ -60,6 +60,13 @@ int xr_tune(int knob, int value);
  * dst holds the planes back to back: [nplanes][A1*A2][Kg] bf16. */
 int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int taps, int B, int Bp, int Kg,
                    int64_t sa1, int64_t sa2, int64_t st, int64_t sb, void* stream);
+/* Batched refresh: a training step re-packs every convolution weight after the optimizer update (~110 small launches for
+ * IR-SE-50); a plan turns them into one launch.  entries: n x 14 int64 host words per parameter
+ * {src, dst, nplanes, A1, A2, taps, B, Bp, Kg, sa1, sa2, st, sb, 0} with xr_pack_weight's meaning; xr_pack_plan writes the
+ * device table (n * 128 bytes at table_dev), stores the dynamic-LDS size in *smem_out and returns the grid size;
+ * xr_pack_run(table_dev, n, blocks, smem) then refreshes all packs from the current parameter values. */
+int xr_pack_plan(const int64_t* entries, int n, void* table_dev, int* smem_out, void* stream);
+int xr_pack_run(const void* table_dev, int n, int blocks, int smem, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution (MFMA 32x32x16 bf16, LDS-staged NHWC tiles).

@@ -51,15 +51,21 @@ def apply(kvs):
 for _ in range(3):
     step()
 res = {n: [] for n, _ in variants}
+cpu = {}
 for rnd in range(int(os.environ.get("ROUNDS", 4))):
     for name, kvs in variants:
         apply(kvs)
-        step(); torch.cuda.synchronize()
+        for _ in range(int(os.environ.get('SWITCH_WARM', 3))):
+            step()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(4):
             step()
+        t1 = time.perf_counter()
         torch.cuda.synchronize()
         res[name].append((time.perf_counter() - t0) / 4 * 1e3)
+        cpu.setdefault(name, []).append((t1 - t0) / 4 * 1e3)
 for name, v in res.items():
     v = sorted(v)
-    print(f"{name:12s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f}  max {v[-1]:.3f}")
+    c = sorted(cpu[name])
+    print(f"{name:12s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f}  max {v[-1]:.3f}   (host enqueue {c[len(c)//2]:.3f} ms/step)")
