@@ -562,7 +562,7 @@ constexpr size_t igemm_smem() {
 }
 
 }  // namespace
-int g_tune[8] = {3, 1, 0, 0, 1, 1, 18, 1};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible
+int g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible
 namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
@@ -1277,7 +1277,7 @@ extern "C" int xr_pack_run(const void* table_dev, int n, int blocks, int smem, v
 }
 
 extern "C" int xr_tune(int knob, int value) {
-  XR_CHECK_ARG(knob >= 0 && knob < 8, "xr_tune: knob out of range");
+  XR_CHECK_ARG(knob >= 0 && knob < 16, "xr_tune: knob out of range");
   g_tune[knob] = value;
   return XR_OK;
 }

@@ -9,6 +9,8 @@
 // 23-46,56-66,76-91,141-148; model/resnet.py:24-47,159,167,173.
 #include "xr_common.h"
 
+extern int g_tune[16];  // [8] xr_group_stats target blocks, [9] xr_affine_act_bwd_reduce target blocks (xr_conv.hip)
+
 namespace {
 
 constexpr int NT = 256;
@@ -593,7 +595,7 @@ static int check_geo(const char* name, int dtype, int G, int rows, int C) {
 extern "C" int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C, void* stream) {
   if (int e = check_geo("xr_group_stats", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && sums, "xr_group_stats: null pointer");
-  Geo geo = make_geo(G, rows, C, 2048);
+  Geo geo = make_geo(G, rows, C, g_tune[8]);
   const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
   if (dtype == XR_BF16)
     hipLaunchKernelGGL(group_stats_kernel<bf16_t>, geo_grid(geo), dim3(NT), smem, (hipStream_t)stream, (const bf16_t*)x, sums, geo);
@@ -644,7 +646,7 @@ extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* s
   XR_CHECK_ARG(x && dy && red, "xr_affine_act_bwd_reduce: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_reduce: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, nullptr, dy, red, nullptr, nullptr, nullptr, coef_per_group, nullptr};
-  Geo geo = make_geo(G, rows, C, 2048);
+  Geo geo = make_geo(G, rows, C, g_tune[9]);
   const size_t smem = (size_t)(geo.rpb > 12 ? geo.rpb : 12) * C * sizeof(float);
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_bwd_reduce_kernel<bf16_t>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_reduce");
