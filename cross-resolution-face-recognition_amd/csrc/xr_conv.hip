@@ -562,7 +562,7 @@ constexpr size_t igemm_smem() {
 }
 
 }  // namespace
-int g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible
+int g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
 namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
@@ -662,6 +662,28 @@ __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int pitch,
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// same fetch from an unpadded image (row = R bytes, a power of two >= 128) whose 16-B chunks were XOR-swizzled on the way in
+// (LDS-DMA writes lane-linear rows, so the swizzle lives in the DMA source chunk and here): one ds_read_b64_tr_b16 half
+// (32 lanes) touches 4 pixel rows x 64 B, and the swizzle puts those four 64-B segments on distinct quarters of the 256-B
+// bank row -- R >= 256: chunk ^= (row & 3) << 2;  R == 128: chunk ^= ((row >> 1) & 1) << 2
+template <int R>
+__device__ __forceinline__ int wg_swz(int row) { return R >= 256 ? (row & 3) << 2 : ((row >> 1) & 1) << 2; }
+template <int R>
+__device__ __forceinline__ bf16x8_t tr_frag_sw(const unsigned char* img, int pix0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int q = i >> 2, pp = i & 3;
+  const int cgrp = g & 1, h = g >> 1;
+  const int row = pix0 + 8 * h + q;                 // row + 4 has the same swizzle term
+  const int cb = (col0 + 16 * cgrp + 4 * pp) * 2;   // byte column of this lane's 8-B packet
+  const int byte = row * R + ((((cb >> 4) ^ wg_swz<R>(row)) << 4) | (cb & 15));
+  typedef s16x4_t __attribute__((address_space(3))) * lds_v4;
+  s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(img + byte));
+  s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(img + byte + 4 * R));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // FAST (forward-gather only): the per-slot pixel cursor (n, ho, wo) is advanced incrementally by the scalar
 // decomposition of 64 pixels instead of being re-derived with two divisions per row per step, and both operands
 // come in through buffer loads whose range check supplies the zero padding.
@@ -671,7 +693,11 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int NS = MODE ? 3 : 1;
   constexpr int WC = BC / 64, WR = BR / 64;  // wave grid (wave tile 64x64)
   static_assert(WC * WR == 4, "4 waves");
-  constexpr int PY = BR * 2 + 64, PX = BC * 2 + 64;  // image pitches: == 64 (mod 256) -> conflict-free tr reads
+  // NBUF == 2 on the bf16 FAST path = LDS-DMA staging: both images go global -> LDS by buffer_load ... lds (no staging
+  // VGPRs, no ds_write -- the LDS write port, ~80 B/clk, is the busiest unit of the register-staged variant), double
+  // buffered, unpadded rows with the chunk swizzle of tr_frag_sw
+  constexpr bool DMA = NBUF == 2 && FAST && MODE == 0;
+  constexpr int PY = DMA ? BR * 2 : BR * 2 + 64, PX = DMA ? BC * 2 : BC * 2 + 64;  // padded pitches: == 64 (mod 256) -> conflict-free tr reads
   constexpr int CRY = BR / 8, CRX = BC / 8;          // chunks per image row
   constexpr int NY = BP * CRY / NT, NX = BP * CRX / NT;
   using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
@@ -694,14 +720,16 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   const in_t* __restrict__ in = reinterpret_cast<const in_t*>(p.in);
   const in_t* __restrict__ dy = reinterpret_cast<const in_t*>(p.dy);
 
-  // X-gather column decode: fixed per thread for the whole kernel
-  const int xch = t % CRX, xrow0 = t / CRX;
+  // X-gather column decode: fixed per thread for the whole kernel (with DMA staging the thread's LDS slot is fixed and it
+  // fetches the source chunk that the swizzle maps into that slot; the row term is the same for all of a thread's rows)
+  const int xrow0 = t / CRX, yrow0 = t / CRY;
+  const int xch = DMA ? (t % CRX) ^ wg_swz<PX>(xrow0) : t % CRX;
+  const int ych = DMA ? (t % CRY) ^ wg_swz<PY>(yrow0) : t % CRY;
   const int j0 = c0 + xch * 8;
   const int tap = j0 / p.C;
   const int cch = j0 - tap * p.C;
   const int tr_ = tap / p.S, ts_ = tap - tr_ * p.S;
   const bool col_ok = (tap < p.R * p.S) && (j0 < p.Kg);
-  const int ych = t % CRY, yrow0 = t / CRY;
   const bool ycol_ok = (r0 + ych * 8) < p.ldy;
 
   float y_f[MODE ? NY : 1][8], x_f[MODE ? NX : 1][8];
@@ -767,6 +795,38 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       if (w >= p.Wo) { w -= p.Wo; ++h; }
       if (h >= p.Ho) { h -= p.Ho; ++n; }
       xw[i] = w; xh[i] = h; xn[i] = n;
+    }
+  };
+
+  auto dma_stage = [&](int step, int buf) {
+    if constexpr (DMA) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef __attribute__((address_space(3))) void* lds_ptr_t;
+      unsigned char* sY = smem + buf * STAGE;
+      unsigned char* sX = sY + BP * PY;
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const int mbase = step * BP;
+      const unsigned ysoff = (unsigned)mbase * (unsigned)(p.ldy * ESZ);
+#pragma unroll
+      for (int i = 0; i < NY; ++i) {
+        const int m = mbase + yrow0 + (NT / CRY) * i;
+        const unsigned voff = m < p.M ? y_base[i] : XR_OOR;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_ptr_t)(sY + (wv * (64 / CRY) + (NT / CRY) * i) * PY), 16, voff, ysoff, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int hi = xh[i] * p.stride - p.pad + tr_, wi = xw[i] * p.stride - p.pad + ts_;
+        const bool ok = col_ok && xn[i] < p.N && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const unsigned voff = ok ? (unsigned)((((xn[i] * p.H + hi) * p.W + wi) * p.C + cch) * ESZ) : XR_OOR;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + (wv * (64 / CRX) + (NT / CRX) * i) * PX), 16, voff, 0, 0, 0);
+        int w = xw[i] + p.c64, h = xh[i] + p.b64, n = xn[i] + p.a64;
+        if (w >= p.Wo) { w -= p.Wo; ++h; }
+        if (h >= p.Ho) { h -= p.Ho; ++n; }
+        xw[i] = w; xh[i] = h; xn[i] = n;
+      }
+#else
+      (void)step; (void)buf;
+#endif
     }
   };
 
@@ -860,11 +920,13 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fa[i][s] = tr_frag(sY + s * BP * PY, PY, ks * 16, wr0 + i * 32, lane);
+        for (int s = 0; s < NS; ++s)
+          fa[i][s] = DMA ? tr_frag_sw<PY>(sY, ks * 16, wr0 + i * 32, lane) : tr_frag(sY + s * BP * PY, PY, ks * 16, wr0 + i * 32, lane);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fb[j][s] = tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
+        for (int s = 0; s < NS; ++s)
+          fb[j][s] = DMA ? tr_frag_sw<PX>(sX, ks * 16, wc0 + j * 32, lane) : tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
       if (p.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -876,7 +938,18 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 
   if (s_begin < s_end) {
     init_cursor(s_begin);
-    if constexpr (NBUF == 2) {
+    if constexpr (DMA) {
+      // stage s lives in buffer (s - s_begin) & 1; the DMA of stage s+1 is issued before the MFMAs of stage s, and the
+      // barrier (hipcc drains vmcnt(0) in front of it because LDS-DMA is pending) orders RAW and WAR
+      dma_stage(s_begin, 0);
+      __syncthreads();
+      for (int step = s_begin; step < s_end; ++step) {
+        const int buf = (step - s_begin) & 1;
+        if (step + 1 < s_end) dma_stage(step + 1, buf ^ 1);
+        compute_stage(buf);
+        __syncthreads();
+      }
+    } else if constexpr (NBUF == 2) {
       load_stage(s_begin);
       store_stage(0);
       __syncthreads();
@@ -932,6 +1005,13 @@ int launch_wgrad(WgradP& p, int split, hipStream_t st) {
   p.b64 = (64 % howo) / p.Wo;
   p.c64 = (64 % howo) % p.Wo;
   if constexpr (!TR) {
+    if constexpr (MODE == 0) {
+      // LDS-DMA staging: measured per layer shape (tools/conv_bench.py) -- pays on the stride-1 gathers with >= 128 input
+      // channels and on all >= 256-channel layers, loses on the strided / 64-channel gathers except 64 -> 64 stride 1
+      const bool dma = g_tune[11] == 2 ||
+                       (g_tune[11] == 1 && (p.C >= 256 || (p.stride == 1 && (p.C >= 128 || p.K <= 64))));
+      if (fast && dma) return launch_wgrad_nb<MODE, BR, BC, TR, 2, true>(p, split, st);
+    }
     if (fast) return launch_wgrad_nb<MODE, BR, BC, TR, 1, true>(p, split, st);
   }
   return launch_wgrad_nb<MODE, BR, BC, TR, 1, false>(p, split, st);
@@ -940,7 +1020,8 @@ int launch_wgrad(WgradP& p, int split, hipStream_t st) {
 template <int MODE, int BR, int BC, bool TR, int NBUF, bool FAST>
 int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
   constexpr int NS = MODE ? 3 : 1;
-  constexpr size_t smem = (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64)) * NBUF;
+  constexpr bool DMA = NBUF == 2 && FAST && MODE == 0;
+  constexpr size_t smem = DMA ? (size_t)2 * 64 * (BR * 2 + BC * 2) : (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64)) * NBUF;
   p.fd_howo = make_fd((unsigned)(p.Ho * p.Wo));
   p.fd_wo = make_fd((unsigned)p.Wo);
   p.tiles_c = cdiv(p.Kg, BC);
