@@ -29,14 +29,12 @@ typedef unsigned v4u8_t __attribute__((ext_vector_type(4)));
 
 template <int N>
 __device__ __forceinline__ void vmcnt_le() {  // wait until at most N of this wave's vector-memory operations are pending
-  static_assert(N >= 0 && N <= 6, "unexpected DMA count");
+  static_assert(N >= 0 && N <= 12, "unexpected DMA count");
+#define XR8_VM(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  XR8_VM(1); XR8_VM(2); XR8_VM(3); XR8_VM(4); XR8_VM(5); XR8_VM(6); XR8_VM(7); XR8_VM(8); XR8_VM(9); XR8_VM(10); XR8_VM(11);
+  XR8_VM(12);
+#undef XR8_VM
 }
 
 __device__ __forceinline__ bf16x8_t lds_read16(unsigned addr) {
@@ -66,7 +64,7 @@ struct Cfg8 {
   static_assert(2 * BUF >= 8 * IMG, "epilogue images must fit in the operand buffers");
 };
 
-template <bool TR, int WRN, int MB, int MB1>
+template <bool TR, int WRN, int MB, int MB1, bool DEEP>
 __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   using C8 = Cfg8<WRN, MB, MB1>;
   constexpr int WCN = C8::WCN, QR = C8::QR, WTR = C8::WTR, BN8 = C8::BN, BUF8 = C8::BUF, BOFF8 = C8::BOFF;
@@ -136,6 +134,8 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   int st_ti = 0, st_rr = 0, st_ss = 0, st_c0 = 0;
   int dby = 0, wk2 = 0;
   unsigned sh = 0;
+  int dby_b = 0, wk2_b = 0;   // DEEP: (dby, wk2, sh) address K-tile t+2 (the A0 / B0 quarters), the _b set K-tile t+1 (B1 / A1)
+  unsigned sh_b = 0;
   auto cursor_eval = [&]() {
     int dpix = st_rr * p.W + st_ss;
     if (TR) dpix = -dpix;
@@ -152,27 +152,30 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
     }
   };
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto dma_A = [&](int buf, int mi) {
+  auto dma_A = [&](int buf, int mi, bool lag = false) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned sh_ = lag ? sh_b : sh;
+    const int dby_ = lag ? dby_b : dby;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      const unsigned voff = ((a_msk[mi][i] >> sh) & 1u) ? (unsigned)(a_off[mi][i] + dby) : XR8_OOR;
+      const unsigned voff = ((a_msk[mi][i] >> sh_) & 1u) ? (unsigned)(a_off[mi][i] + dby_) : XR8_OOR;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(smem + buf * BUF8 + a_piece_row(mi, i) * 128), 16, voff, 0, 0, 0);
     }
 #else
-    (void)buf; (void)mi;
+    (void)buf; (void)mi; (void)lag;
 #endif
   };
-  auto dma_B = [&](int buf, int ni) {
+  auto dma_B = [&](int buf, int ni, bool lag = false) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    const int wk_ = lag ? wk2_b : wk2;
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int g = wid + 8 * i;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsB, (lds_ptr_t)(smem + buf * BUF8 + BOFF8 + ((g >> 2) * 64 + ni * 32 + (g & 3) * 8) * 128), 16, b_off[ni][i], wk2, 0, 0);
+          rsB, (lds_ptr_t)(smem + buf * BUF8 + BOFF8 + ((g >> 2) * 64 + ni * 32 + (g & 3) * 8) * 128), 16, b_off[ni][i], wk_, 0, 0);
     }
 #else
-    (void)buf; (void)ni;
+    (void)buf; (void)ni; (void)lag;
 #endif
   };
 
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   const unsigned ldsA = lds0 + (unsigned)(wr * WTR * 128), ldsB = lds0 + (unsigned)(BOFF8 + wc * 64 * 128);
 
   bf16x8_t fa[MB][2], fb[2][2];
+  bf16x8_t fb0[2][2];  // DEEP keeps the N-half-0 fragments for phase 3 instead of re-reading them (frees the B0 quarter early)
   f32x4_t acc[2][MB][4];  // [M-half][16-row block][16-col block]: lane holds pixel l&15, channels 4*(l>>4)..+3
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -215,6 +219,91 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   __builtin_amdgcn_sched_barrier(0);
 
   const int nk = p.Kg >> 6;
+  if constexpr (DEEP) {
+    // Deeper prefetch (5-6 phases instead of 3-4; four quarter tiles in flight): a quarter is refilled two phases after its
+    // last read -- with the NEXT-BUT-ONE K-tile for A0 / B0 (same buffer), the next K-tile for B1 / A1 (other buffer):
+    //   phase 0: read B0, A0 | issue B1(t+1) | wait B1(t)        phase 2: read A1 | issue A0(t+2)
+    //   phase 1: read B1     | issue A1(t+1) | wait A1(t)        phase 3: (B0 from registers) | issue B0(t+2) | wait A0,B0(t+1)
+    // Counted waits leave 2 PA + 2 PB pieces in flight while a next K-tile exists.
+#define XR8_RD_B0(buf)                                                                           \
+  _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) \
+      fb0[nb][ks] = lds_read16((unsigned)((buf) * BUF8) + ldsB + (unsigned)((nb * 16) * 128) + rd[ks]);
+#define XR8_MMA_B0(mi)                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+  __builtin_amdgcn_sched_barrier(0);                                                                          \
+  __builtin_amdgcn_s_setprio(1);                                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int mb = 0; mb < ((mi) ? MB1 : MB); ++mb) \
+      _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc[mi][mb][nb] =                                      \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb0[nb][ks], fa[mb][ks], acc[mi][mb][nb], 0, 0, 0);          \
+  __builtin_amdgcn_s_setprio(0);                                                                              \
+  __builtin_amdgcn_sched_barrier(0);
+    cursor_eval();              // K-tile 0
+    dma_A(0, 0);
+    dma_B(0, 0);
+    dma_B(0, 1);
+    dma_A(0, 1);
+    if (nk > 1) {
+      cursor_next();
+      cursor_eval();            // K-tile 1
+      dma_A(1, 0);
+      dma_B(1, 0);
+      vmcnt_le<2 * PA + 2 * PB>();
+    } else {
+      vmcnt_le<PA + PB>();
+    }
+    XR8_BAR();
+    if (grp == 1) { XR8_BAR(); }
+    for (int kk = 0; kk < nk; ++kk) {
+      const int buf = kk & 1, nbuf = buf ^ 1;
+      const bool n1 = kk + 1 < nk, n2 = kk + 2 < nk;
+      // cursor bookkeeping: (dby, wk2, sh) currently describe K-tile kk+1 (when it exists); keep them as the lagging set and
+      // advance the leading set to K-tile kk+2
+      dby_b = dby; wk2_b = wk2; sh_b = sh;
+      if (n2) {
+        cursor_next();
+        cursor_eval();
+      }
+      // ---- phase 0
+      XR8_RD_B0(buf);
+      XR8_RD_A(buf, 0);
+      if (n1) {
+        dma_B(nbuf, 1, true);
+        vmcnt_le<2 * PA + 2 * PB>();
+      } else {
+        vmcnt_le<PA>();
+      }
+      XR8_BAR();
+      XR8_MMA_B0(0);
+      XR8_BAR();
+      // ---- phase 1
+      XR8_RD_B(buf, 1);
+      if (n1) {
+        dma_A(nbuf, 1, true);
+        vmcnt_le<2 * PA + 2 * PB>();
+      } else {
+        vmcnt_le<0>();
+      }
+      XR8_BAR();
+      XR8_MMA(0, 1);
+      XR8_BAR();
+      // ---- phase 2
+      XR8_RD_A(buf, 1);
+      if (n2) dma_A(buf, 0);
+      XR8_BAR();
+      XR8_MMA(1, 1);
+      XR8_BAR();
+      // ---- phase 3
+      if (n2) {
+        dma_B(buf, 0);
+        vmcnt_le<2 * PA + 2 * PB>();
+      } else if (n1) {
+        vmcnt_le<PA + PB>();
+      }
+      XR8_BAR();
+      XR8_MMA_B0(1);
+      XR8_BAR();
+    }
+  } else {
   // prologue: K-tile 0 into buffer 0 in the order the loop keeps (A0, B0, B1, A1)
   cursor_eval();
   dma_A(0, 0);
@@ -265,6 +354,7 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
     XR8_BAR();
     XR8_MMA(1, 0);
     XR8_BAR();
+  }
   }
   if (grp == 0) { XR8_BAR(); }  // re-align the two groups: every operand read is retired, LDS is free for the epilogue
 
@@ -387,15 +477,15 @@ static int igemm8_config(const IgemmP& p, int dtype, int transposed) {
 
 bool xr_igemm8_eligible(const IgemmP& p, int dtype, int transposed) { return igemm8_config(p, dtype, transposed) != 0; }
 
-template <bool TR, int WRN, int MB, int MB1 = MB>
-static int igemm8_launch_cfg(IgemmP& p, hipStream_t st) {
+template <bool TR, int WRN, int MB, int MB1, bool DEEP>
+static int igemm8_launch_cfg2(IgemmP& p, hipStream_t st) {
   using C8 = Cfg8<WRN, MB, MB1>;
   p.tiles_n = cdiv((p.K + 7) / 8 * 8, C8::BN);
   const int tiles_m = cdiv(p.M, C8::BMV);
   p.fd_tn = make_fd((unsigned)p.tiles_n);
   constexpr int smem = 2 * C8::BUF;
   static bool attr_done = false;
-  auto kern = igemm8_kernel<TR, WRN, MB, MB1>;
+  auto kern = igemm8_kernel<TR, WRN, MB, MB1, DEEP>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
@@ -407,6 +497,12 @@ static int igemm8_launch_cfg(IgemmP& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT8), smem, st, p);
   XR_CHECK_LAUNCH("xr_conv_igemm(8-wave)");
   return XR_OK;
+}
+
+template <bool TR, int WRN, int MB, int MB1 = MB>
+static int igemm8_launch_cfg(IgemmP& p, hipStream_t st) {
+  if (g_tune[12]) return igemm8_launch_cfg2<TR, WRN, MB, MB1, true>(p, st);
+  return igemm8_launch_cfg2<TR, WRN, MB, MB1, false>(p, st);
 }
 
 int xr_igemm8_launch(IgemmP& p, int transposed, hipStream_t st) {

@@ -91,9 +91,10 @@ CONV8_CASES = [
 ]
 
 
+@pytest.mark.parametrize("deep", [0, 1])   # knob 12: prefetch schedule (3-4 / 5-6 phases ahead)
 @pytest.mark.parametrize("cfg", [3, 4, 5, 6, 7, 8])   # xr_tune knob 7: force tile configuration 256x256, 256x128, 128x256, 224x256, 512x128, 448x128
 @pytest.mark.parametrize("case", CONV8_CASES)
-def test_conv2d_8wave_kernel(case, cfg):
+def test_conv2d_8wave_kernel(case, cfg, deep):
     """xr_conv8.hip (8-wave ping-pong tile) against the fp32 CPU conv: forward, input gradient (same kernel, transposed
     gather) and -- unchanged kernel, sanity only -- the weight gradient."""
     from xrface import ops
@@ -109,6 +110,7 @@ def test_conv2d_8wave_kernel(case, cfg):
     gy = rnd(f"c8g{case}", *y_ref.shape)
     y_ref.backward(gy)
     lib.xr_tune(7, cfg)
+    lib.xr_tune(12, deep)
     try:
         xg = x.to(DEV).requires_grad_(True)
         wg = w.to(DEV).requires_grad_(True)
@@ -119,6 +121,7 @@ def test_conv2d_8wave_kernel(case, cfg):
         torch.cuda.synchronize()
     finally:
         lib.xr_tune(7, 1)
+        lib.xr_tune(12, 1)
     tol = TOL[torch.bfloat16]
     assert rel(y, y_ref) < tol
     assert rel(xg.grad, xr.grad) < tol
