@@ -135,6 +135,53 @@ def test_conv2d_8wave_kernel(case, cfg, deep):
     assert rel(y, y4) < 1e-2
 
 
+@pytest.mark.parametrize("shape", [(256, 256, 256, 14, 1), (128, 128, 128, 28, 1), (64, 256, 512, 14, 1), (32, 128, 256, 28, 2)])
+def test_conv2d_8wave_race_screen(shape):
+    """The 8-wave kernel orders its LDS-DMA prefetch by counted vmcnt + raw barriers only, so a wrong count would show up
+    as a rare wrong tile.  Screen at the benchmark's full sizes: 60 back-to-back launches (forward and transposed gather,
+    both prefetch schedules) must reproduce the first launch bit for bit, and the first launch must agree with the 4-wave
+    kernel up to accumulation order."""
+    from xrface import ops
+    from xrface._lib import lib, ptr, stream, dt
+    N, C, K, H, st = shape
+    Ho = (H + 2 - 3) // st + 1
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn(N, H, H, C, device=DEV, generator=g).bfloat16()
+    dy = torch.randn(N, Ho, Ho, K, device=DEV, generator=g).bfloat16()
+    w = torch.randn(K, C, 3, 3, device=DEV, generator=g) * 0.05
+    pk, kg = ops._packed(w, "fwd", torch.bfloat16, K, 1, 9, C, C, C * 9, 0, 1, 9)
+    pkd, kgd = ops._packed(w, "dgrad", torch.bfloat16, C, 1, 9, K, K, 9, 0, 1, C * 9)
+
+    def fwd(out):
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(out), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None,
+                          None, 1, stream())
+
+    def dgrad(out):
+        lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(out), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None,
+                          None, 1, stream())
+
+    try:
+        lib.xr_tune(7, 0)
+        y4, dx4 = torch.empty_like(dy), torch.empty_like(x)
+        fwd(y4); dgrad(dx4)
+        for deep in (0, 1):
+            lib.xr_tune(7, 2)
+            lib.xr_tune(12, deep)
+            y0, dx0 = torch.empty_like(dy), torch.empty_like(x)
+            fwd(y0); dgrad(dx0)
+            assert rel(y0, y4) < 1e-2 and rel(dx0, dx4) < 1e-2
+            bad = 0
+            ys, dxs = [torch.empty_like(dy) for _ in range(4)], [torch.empty_like(x) for _ in range(4)]
+            for it in range(60):
+                fwd(ys[it % 4]); dgrad(dxs[it % 4])
+                if it % 4 == 3:
+                    bad += sum(int(not torch.equal(t, y0)) for t in ys) + sum(int(not torch.equal(t, dx0)) for t in dxs)
+            assert bad == 0, f"{bad} launches differ from the first one (prefetch schedule deep={deep})"
+    finally:
+        lib.xr_tune(7, 1)
+        lib.xr_tune(12, 1)
+
+
 def test_conv2d_8wave_prelu_backward_epilogue():
     """dgrad of conv(prelu(y)) with the PReLU backward fused into the 8-wave kernel's epilogue."""
     from xrface import ops
