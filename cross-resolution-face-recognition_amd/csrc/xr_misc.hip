@@ -282,7 +282,8 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask, T* __restrict__ y, int64_t n, float p,
-                               uint64_t seed) {
+                               uint64_t seed, const uint64_t* __restrict__ tick) {
+  if (tick != nullptr) seed = mix64(seed + *tick * 0x9E3779B97F4A7C15ull);  // replayed HIP graph: the step counter lives on the device
   const float sc = 1.f / (1.f - p);
   const uint32_t thr = (uint32_t)((double)p * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)p * 4294967296.0);
   GRID_STRIDE(i, n) {
@@ -527,7 +528,13 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
   }
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                            int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2) {
+                            int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, int step,
+                            const uint64_t* __restrict__ tick, uint64_t tick_ref) {
+  if (tick != nullptr) {  // replayed HIP graph: the bias corrections follow the device-side step counter
+    const float st = (float)(step + (int)(*tick - tick_ref));
+    bc1 = 1.f - powf(b1, st);
+    bc2 = 1.f - powf(b2, st);
+  }
   GRID_STRIDE(i, n) {
     float gi = g[i];
     if (wd != 0.f) gi += wd * p[i];
@@ -738,12 +745,12 @@ extern "C" int xr_sub(int dtype, const void* a, const void* b, void* y, int64_t 
   return addsub(dtype, a, b, y, n, -1.f, stream, "xr_sub");
 }
 extern "C" int xr_dropout(int dtype, const void* x, const uint8_t* mask, void* y, int64_t n, float p, uint64_t seed,
-                          void* stream) {
+                          const void* tick, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_dropout: bad dtype");
   XR_CHECK_ARG(x && y && n > 0 && p >= 0.f && p < 1.f, "xr_dropout: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   XR_DISPATCH(dtype, hipLaunchKernelGGL(dropout_kernel<T>, dim3(grid_for(n)), dim3(NT), 0, st, (const T*)x, mask, (T*)y, n, p,
-                                        (uint64_t)seed));
+                                        (uint64_t)seed, (const uint64_t*)tick));
   XR_CHECK_LAUNCH("xr_dropout");
   return XR_OK;
 }
@@ -843,11 +850,11 @@ extern "C" int xr_rmsprop_step(float* p, const float* g, float* sq, int64_t n, f
   return XR_OK;
 }
 extern "C" int xr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                            float wd, int step, void* stream) {
+                            float wd, int step, const void* tick, int64_t tick_ref, void* stream) {
   XR_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "xr_adam_step: bad arguments");
   const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, NT * 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, wd,
-                     bc1, bc2);
+                     bc1, bc2, step, (const uint64_t*)tick, (uint64_t)tick_ref);
   XR_CHECK_LAUNCH("xr_adam_step");
   return XR_OK;
 }

@@ -1,0 +1,57 @@
+"""Whole-step HIP graphs.
+
+The small-batch steps of this code base (FSRNet at N = 4-32, the per-pair FHN loop, the KD step at N = 64) are launch-bound:
+700-3000 kernels of a few microseconds each, 10-30 ms of host time per step.  ``GraphedStep`` captures one complete step --
+forward, backward, optimizer update, BatchNorm counter bumps, weight re-packs -- into a single HIP graph and replays it with
+~0.3 ms of host work.  Everything the step reads from the host must be frozen or moved to the device:
+
+* inputs live in static tensors (``__call__`` copies the new batch in);
+* the zero-initialised scratch slab (statistic sums, loss scalars) is created inside the capture, so its memset is a
+  graph node and every replay starts from zeros;
+* dropout mixes a device-side step counter into its seed (``xr_dropout``'s ``tick``), incremented by the graph;
+* FusedAdam's bias corrections follow the same device counter; hyper-parameters passed by value (learning rate) are
+  frozen: re-capture after changing them.  Steps taken by replays are not reflected in the optimizer's host-side counter.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class GraphedStep:
+    def __init__(self, fn, example_inputs, warmup: int = 3):
+        """fn(*tensors) -> tensor | tuple of tensors | None runs one full step; it must not synchronise with the host."""
+        assert all(t.is_cuda for t in example_inputs), "GraphedStep: inputs must be device tensors"
+        self.static_in = [t.clone() for t in example_inputs]
+        dev = self.static_in[0].device if self.static_in else torch.device("cuda", torch.cuda.current_device())
+        cur = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):   # warm-up: lazy initialisation, weight-pack tables, allocator pools
+            for _ in range(warmup):
+                fn(*self.static_in)
+        cur.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        if ops._graph["tick"] is None or ops._graph["tick"].device != dev:
+            ops._graph["tick"] = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.tick = ops._graph["tick"]
+        ops._graph["tick_ref"] = int(self.tick.item()) + 1   # the value the first replay sees
+        self.graph = torch.cuda.CUDAGraph()
+        ops._zpool.buf = None
+        ops._graph["capturing"] = True
+        try:
+            with torch.cuda.graph(self.graph):
+                self.tick.add_(1)
+                self.static_out = fn(*self.static_in)
+        finally:
+            ops._graph["capturing"] = False
+            ops._zpool.buf = None   # the slab captured above belongs to the graph's memory pool
+
+    def __call__(self, *inputs):
+        assert len(inputs) == len(self.static_in)
+        for s, t in zip(self.static_in, inputs):
+            if s.data_ptr() != t.data_ptr():
+                s.copy_(t, non_blocking=True)
+        self.graph.replay()
+        return self.static_out

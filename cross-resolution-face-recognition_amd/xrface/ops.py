@@ -77,6 +77,10 @@ class _ZeroPool:
 
 _zpool = _ZeroPool()
 
+# HIP-graph capture state (xrface.graph.GraphedStep): while a step is being captured, the zero slab is re-created inside the
+# capture (so every replay re-zeroes it) and dropout reads a device-side step counter that the graph itself increments
+_graph = {"capturing": False, "tick": None, "tick_ref": 0}
+
 
 def zeros_f32(shape, device):
     return _zpool.get(tuple(shape) if not isinstance(shape, int) else (shape,), device)
@@ -154,53 +158,58 @@ def _pack_tag(w):
 
 
 class _PackPlan:
-    """Every (parameter, pack form) seen so far, refreshed by ONE launch (xr_pack_run) when any of them went stale --
-    instead of ~110 per-layer pack launches after each optimizer step.  Pack buffers are persistent: a refresh overwrites
-    them in stream order, after every kernel of the previous step that read them."""
+    """Every (parameter, pack form) seen so far; when a registered pack is found stale, ALL stale registered packs are
+    refreshed by ONE launch (xr_pack_run over a device descriptor table) -- instead of ~110 per-layer pack launches after
+    each optimizer step.  Tables are cached per stale set (a training loop has a few: {student}, {assistant}, ...; packs of
+    a frozen teacher are never stale and never re-packed).  Pack buffers are persistent: a refresh overwrites them in
+    stream order, after every kernel of the previous step that read them."""
 
     def __init__(self):
         self.entries = []     # [weakref(w), key, pk, kg, args]
         self.index = {}       # (id(w), key) -> entry
-        self.table = None
-        self.meta = None      # (n, blocks, smem)
-        self.ptrs = None      # source pointers the table was built for
+        self.tables = {}      # tuple(entry ids) -> (table, (n, blocks, smem), [src ptrs])
 
     def add(self, w, key, pk, kg, args):
         e = [weakref.ref(w), key, pk, kg, args]
         self.entries.append(e)
         self.index[(id(w), key)] = e
-        self.table = None
 
-    def _build(self, live):
+    def _build(self, sel):
         import numpy as np
-        ent = np.zeros((len(live), 14), dtype=np.int64)
-        for i, (w, e) in enumerate(live):
+        ent = np.zeros((len(sel), 14), dtype=np.int64)
+        for i, (w, e) in enumerate(sel):
             planes, A1, A2, taps, B, Bp, sa1, sa2, st, sb = e[4]
             ent[i] = (w.data_ptr(), e[2].data_ptr(), planes, A1, A2, taps, B, Bp, e[3], sa1, sa2, st, sb, 0)
-        self.table = torch.empty(len(live) * 128, dtype=torch.uint8, device=live[0][0].device)
+        table = torch.empty(len(sel) * 128, dtype=torch.uint8, device=sel[0][0].device)
         smem = ctypes.c_int(0)
-        blocks = lib.xr_pack_plan(ent.ctypes.data, len(live), ptr(self.table), ctypes.addressof(smem), stream())
-        self.meta = (len(live), blocks, smem.value)
-        self.ptrs = [w.data_ptr() for w, _ in live]
+        blocks = lib.xr_pack_plan(ent.ctypes.data, len(sel), ptr(table), ctypes.addressof(smem), stream())
+        return table, (len(sel), blocks, smem.value), [w.data_ptr() for w, _ in sel]
 
     def refresh(self):
-        live = []
+        stale, dead = [], False
         for e in self.entries:
             w = e[0]()
-            if w is not None and w.__dict__.get("_xr_pack", {}).get(e[1], (None, None))[1] is e[2] and w.dtype == torch.float32 \
-                    and w.is_contiguous():
-                live.append((w, e))
-        if len(live) != len(self.entries):
-            self.entries = [e for _, e in live]
-            self.index = {(id(w), e[1]): e for w, e in live}
-            self.table = None
-        if not live:
+            hit = None if w is None else w.__dict__.get("_xr_pack", {}).get(e[1])
+            if hit is None or hit[1] is not e[2] or w.dtype != torch.float32 or not w.is_contiguous():
+                dead = True          # parameter gone / re-packed elsewhere: drop the entry
+                e[0] = None
+            elif hit[0] != _pack_tag(w):
+                stale.append((w, e))
+        if dead:
+            self.entries = [e for e in self.entries if e[0] is not None]
+            self.index = {(id(e[0]()), e[1]): e for e in self.entries}
+            self.tables.clear()
+        if not stale:
             return
-        if self.table is None or self.ptrs != [w.data_ptr() for w, _ in live] or self.table.device != live[0][0].device:
-            self._build(live)
-        n, blocks, smem = self.meta
-        lib.xr_pack_run(ptr(self.table), n, blocks, smem, stream())
-        for w, e in live:
+        key = tuple(id(e) for _, e in stale)
+        ent = self.tables.get(key)
+        if ent is None or ent[2] != [w.data_ptr() for w, _ in stale] or ent[0].device != stale[0][0].device:
+            if len(self.tables) >= 8:
+                self.tables.clear()
+            ent = self.tables[key] = self._build(stale)
+        n, blocks, smem = ent[1]
+        lib.xr_pack_run(ptr(ent[0]), n, blocks, smem, stream())
+        for w, e in stale:
             w.__dict__["_xr_pack"][e[1]] = (_pack_tag(w), e[2], e[3])
 
 
@@ -959,18 +968,19 @@ class _Dropout(Function):
     def forward(ctx, x, p, mask, seed):
         x = _c(x)
         y = torch.empty_like(x)
-        lib.xr_dropout(dt(x), ptr(x), ptr(mask), ptr(y), x.numel(), p, seed, stream())
-        ctx.meta = (p, seed)
+        tick = _graph["tick"] if _graph["capturing"] else None
+        lib.xr_dropout(dt(x), ptr(x), ptr(mask), ptr(y), x.numel(), p, seed, ptr(tick), stream())
+        ctx.meta = (p, seed, tick)
         ctx.save_for_backward(mask)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        p, seed = ctx.meta
+        p, seed, tick = ctx.meta
         (mask,) = ctx.saved_tensors
         dy = _c(dy)
         dx = torch.empty_like(dy)
-        lib.xr_dropout(dt(dy), ptr(dy), ptr(mask), ptr(dx), dy.numel(), p, seed, stream())
+        lib.xr_dropout(dt(dy), ptr(dy), ptr(mask), ptr(dx), dy.numel(), p, seed, ptr(tick), stream())
         return dx, None, None, None
 
 

@@ -195,6 +195,8 @@ class FusedAdam(_FlatOptimizer):
     def step(self, closure=None):
         g = self.param_groups[0]
         self._steps += 1
+        cap = ops._graph["capturing"]
         lib.xr_adam_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.m), ptr(self.v), self.flat.numel, g["lr"],
-                         g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps, stream())
+                         g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps,
+                         ptr(ops._graph["tick"]) if cap else None, ops._graph["tick_ref"] if cap else 0, stream())
         ops.invalidate_weight_cache(self.flat.params)

@@ -212,9 +212,11 @@ int xr_add(int dtype, const void* a, const void* b, void* y, int64_t n, void* st
 int xr_sub(int dtype, const void* a, const void* b, void* y, int64_t n, void* stream);
 
 /* Dropout(p) (model_irse.py:145): y = x*keep/(1-p); keep from `mask` (uint8, optional) or from the
- * counter-based generator hash(seed, element index) -- the same function serves backward. */
+ * counter-based generator hash(seed, element index) -- the same function serves backward.  `tick` (optional device
+ * uint64): mixed into the seed inside the kernel, so a step captured in a HIP graph draws a fresh mask on every replay
+ * (the graph increments the counter; a host-side seed would be frozen into the captured launch). */
 int xr_dropout(int dtype, const void* x, const uint8_t* mask, void* y, int64_t n, float p, uint64_t seed,
-               void* stream);
+               const void* tick, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses: value ACCUMULATED with atomics into loss[0] (fp32, caller zeroes; NULL = gradient-only launch);
@@ -259,7 +261,9 @@ int xr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float
 int xr_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float wd,
                     void* stream);
 int xr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                 float wd, int step, void* stream);
+                 float wd, int step, const void* tick, int64_t tick_ref, void* stream);
+/* `tick` (optional device uint64) / `tick_ref`: inside a captured HIP graph the effective step is
+ * step + (*tick - tick_ref), so the bias corrections advance with the replays (see xr_dropout). */
 
 /* ---------------------------------------------------------------------------------------------
  * Verification (utils/utils.py:14-87, distill_main.py:121-136).

@@ -1,0 +1,140 @@
+"""GPU: whole-step HIP graphs (xrface.graph.GraphedStep) reproduce the eager step."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / max(float(b.double().abs().max()), 1e-30))
+
+
+def _faces(n, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.rand(n, 3, 112, 112, device=DEV, generator=g) * 2 - 1
+
+
+@pytest.mark.parametrize("optname", ["sgd", "adam"])
+def test_graphed_resnet34_step_matches_eager(optname):
+    """Same initial weights, same batches: N replays of the captured step track N eager steps.  Two eager runs of this
+    tiny-batch train-mode network already differ by a few 1e-3 (fp32 atomics order x ill-conditioned BatchNorm), so the
+    bar is 3e-2 on the parameters and 5 % on the losses; exactness of the optimizer under replay is test_graphed_optimizers_exact."""
+    import xrface
+    from xrface import parallel
+    from xrface.graph import GraphedStep
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model.resnet import ResNet_34
+
+    xrface.set_compute_dtype(torch.float32)
+    torch.manual_seed(3)
+    m_e = ResNet_34().to(DEV).train()
+    m_g = copy.deepcopy(m_e)
+    crit = CrossEntropyLoss()
+    y = torch.randint(0, 512, (8,), device=DEV)
+    batches = [_faces(8, s) for s in range(6)]
+
+    def make(model):
+        flat = parallel.FlatParams(model.parameters())
+        if optname == "sgd":
+            opt = parallel.FusedSGD(flat, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        else:
+            opt = parallel.FusedAdam(flat, lr=1e-3, betas=(0.5, 0.999))
+        loss_buf = torch.zeros((), device=DEV)
+
+        def step(x):
+            opt.zero_grad()
+            out = model(x)
+            loss = crit(out[0] if isinstance(out, (tuple, list)) else out, y)
+            loss.backward()
+            opt.step()
+            loss_buf.copy_(loss.detach())
+            return loss_buf
+        return flat, step
+
+    flat_e, step_e = make(m_e)
+    flat_g, step_g = make(m_g)
+    # GraphedStep warms up with 3 eager steps on its example input; give the eager twin the same 3 steps
+    for _ in range(3):
+        step_e(batches[0])
+    gs = GraphedStep(step_g, [batches[0]], warmup=3)
+    assert _rel(flat_g.flat, flat_e.flat) < 3e-2
+    losses_e, losses_g = [], []
+    for x in batches[1:]:
+        losses_e.append(float(step_e(x)))
+        losses_g.append(float(gs(x)))
+    assert _rel(flat_g.flat, flat_e.flat) < 3e-2, (losses_e, losses_g)
+    for a, b in zip(losses_e, losses_g):
+        assert abs(a - b) < 5e-2 * max(1.0, abs(a))
+    sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
+    k = next(k for k in sd_e if k.endswith("num_batches_tracked"))
+    assert int(sd_e[k]) == int(sd_g[k]) == 3 + len(batches) - 1   # BatchNorm counters advance inside the graph too
+
+
+@pytest.mark.parametrize("optname", ["sgd", "rmsprop", "adam"])
+def test_graphed_optimizers_exact(optname):
+    """A deterministic problem (gradient = p - target, no atomics): replays of the captured update equal eager updates to
+    fp32 round-off -- Adam's bias corrections advance with the device-side counter, not with the frozen host step."""
+    from xrface import parallel
+    from xrface.graph import GraphedStep
+
+    torch.manual_seed(5)
+    target = torch.randn(4096, device=DEV)
+
+    def make():
+        p = torch.nn.Parameter(torch.zeros(4096, device=DEV))
+        flat = parallel.FlatParams([p])
+        opt = {"sgd": lambda: parallel.FusedSGD(flat, lr=0.1, momentum=0.9, weight_decay=1e-3),
+               "rmsprop": lambda: parallel.FusedRMSprop(flat, lr=1e-2, alpha=0.9, weight_decay=1e-3),
+               "adam": lambda: parallel.FusedAdam(flat, lr=0.05, betas=(0.8, 0.99))}[optname]()
+
+        def step(t):
+            flat.grad.copy_(flat.flat - t)
+            opt.step()
+            return flat.flat
+        return flat, step
+
+    flat_e, step_e = make()
+    flat_g, step_g = make()
+    for _ in range(2):
+        step_e(target)
+    gs = GraphedStep(step_g, [target], warmup=2)
+    for _ in range(7):
+        step_e(target)
+        gs(target)
+    torch.cuda.synchronize()
+    assert _rel(flat_g.flat, flat_e.flat) < 1e-5
+
+
+def test_graphed_dropout_draws_fresh_masks():
+    """Dropout inside a replayed graph: the keep mask changes from replay to replay (device-side tick) and the backward of
+    each replay uses the mask of its own forward."""
+    import xrface
+    from xrface import ops
+    from xrface.graph import GraphedStep
+
+    xrface.set_compute_dtype(torch.float32)
+    x = torch.ones(8, 4, 4, 64, device=DEV)
+    out = torch.zeros_like(x)
+    grad = torch.zeros_like(x)
+
+    def step(xin):
+        xr = xin.clone().requires_grad_(True)
+        yb = ops.dropout(xr, 0.4, True)
+        yb.sum().backward()
+        out.copy_(yb.detach())
+        grad.copy_(xr.grad)
+        return out
+
+    gs = GraphedStep(step, [x], warmup=2)
+    seen = []
+    for _ in range(4):
+        gs(x)
+        torch.cuda.synchronize()
+        assert torch.equal(out, grad)                       # d(sum)/dx = keep/(1-p) = forward output on an all-ones input
+        keep = float((out != 0).float().mean())
+        assert 0.5 < keep < 0.7
+        seen.append(out.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2]) and not torch.equal(seen[2], seen[3])

@@ -457,7 +457,7 @@ def test_fused_optimizers_match_torch_optim():
             elif kind == "rmsprop":
                 lib.xr_rmsprop_step(ptr(pg), ptr(gg), ptr(s1), n, 5e-3, 0.99, 1e-8, 1e-5, stream())
             else:
-                lib.xr_adam_step(ptr(pg), ptr(gg), ptr(s1), ptr(s2), n, 1e-3, 0.5, 0.999, 1e-8, 1e-5, step, stream())
+                lib.xr_adam_step(ptr(pg), ptr(gg), ptr(s1), ptr(s2), n, 1e-3, 0.5, 0.999, 1e-8, 1e-5, step, None, 0, stream())
         assert rel(pg, pr) < 2e-6, kind
 
 

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 import xrface
 from xrface import parallel, steps
+from xrface.graph import GraphedStep
 from xrface.model import FSRnet, model_irse, resnet
 from xrface.loss.loss import MSELossFunc
 from oracle import detgen as G
@@ -45,6 +46,18 @@ for dtype, n in ((torch.float32, 4), (torch.bfloat16, 4), (torch.bfloat16, 64)):
         opt.step()
     ms = timed(step)
     out[f"C1 coarse N={n} {str(dtype).split('.')[-1]}"] = {"ms": round(ms, 3), "img_s": round(n / ms * 1e3, 1)}
+    try:  # the same step captured in one HIP graph (RMSprop must be capturable)
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-4, alpha=0.99, weight_decay=1e-5, capturable=True)
+        def gstep(lr_, hr_):
+            opt.zero_grad(set_to_none=False)
+            _, img = net(lr_)
+            (12.0 * MSELossFunc()(img, hr_)).backward()
+            opt.step()
+        gs = GraphedStep(gstep, [lr, hr])
+        ms = timed(lambda: gs(lr, hr))
+        out[f"C1 coarse N={n} {str(dtype).split('.')[-1]} HIP graph"] = {"ms": round(ms, 3), "img_s": round(n / ms * 1e3, 1)}
+    except Exception as e:  # noqa: BLE001
+        out[f"C1 coarse N={n} {str(dtype).split('.')[-1]} HIP graph"] = {"error": repr(e)[:200]}
 
 # ---- C3: full FHN step (per-pair gradients), bf16
 xrface.set_compute_dtype(torch.bfloat16)
@@ -56,6 +69,18 @@ hr = faces(n); lr = hr.clone()
 hm = torch.rand(n, 28, 28, device=dev); par = torch.randint(0, 11, (n, 1, 28, 28), device=dev)
 ms = timed(lambda: steps.fhn_step(nets, lr, hr, hm, par, opts), warm=2, reps=3)
 out[f"C3 FHN step N={n} bf16"] = {"ms": round(ms, 2), "img_s": round(n / ms * 1e3, 1)}
+try:
+    opts = {k: torch.optim.RMSprop(v.parameters(), lr=1e-4, alpha=0.99, weight_decay=1e-5, capturable=True) for k, v in nets.items()}
+    def fstep(lr_, hr_, hm_, par_):
+        for o in opts.values():
+            o.zero_grad(set_to_none=False)
+        steps.fhn_step(nets, lr_, hr_, hm_, par_, opts)
+    gs = GraphedStep(fstep, [lr, hr, hm, par], warmup=2)
+    ms = timed(lambda: gs(lr, hr, hm, par), warm=1, reps=3)
+    out[f"C3 FHN step N={n} bf16 HIP graph"] = {"ms": round(ms, 2), "img_s": round(n / ms * 1e3, 1)}
+    del gs
+except Exception as e:  # noqa: BLE001
+    out[f"C3 FHN step N={n} bf16 HIP graph"] = {"error": repr(e)[:300]}
 del nets, opts
 
 # ---- C4-like: residual KD step, teacher IR-50 (frozen) + student/assistant ResNet-34, bf16
@@ -70,6 +95,18 @@ def kd():
     steps.kd_step(teacher, student, assistant, x, so, ao)
 ms = timed(kd, warm=2, reps=3)
 out[f"C4 KD step N={n} bf16"] = {"ms": round(ms, 2), "img_s": round(n / ms * 1e3, 1)}
+try:
+    so = torch.optim.RMSprop(student.parameters(), lr=1e-4, weight_decay=1e-5, capturable=True)
+    ao = torch.optim.RMSprop(assistant.parameters(), lr=1e-4, weight_decay=1e-5, capturable=True)
+    def kstep(x_):
+        so.zero_grad(set_to_none=False); ao.zero_grad(set_to_none=False)
+        steps.kd_step(teacher, student, assistant, x_, so, ao)
+    gs = GraphedStep(kstep, [x], warmup=3)
+    ms = timed(lambda: gs(x), warm=1, reps=5)
+    out[f"C4 KD step N={n} bf16 HIP graph"] = {"ms": round(ms, 2), "img_s": round(n / ms * 1e3, 1)}
+    del gs
+except Exception as e:  # noqa: BLE001
+    out[f"C4 KD step N={n} bf16 HIP graph"] = {"error": repr(e)[:300]}
 del teacher, student, assistant
 
 # ---- C5: P = 1e6 pair distances + 4000-threshold / 10-fold ROC

@@ -25,6 +25,21 @@ def step():
     opt.zero_grad(); crit(model(x), y).backward(); opt.step()
 
 
+if os.environ.get("WORKLOAD") == "kd":  # residual KD step (BASELINE config 4 shape): IR-50 teacher + 2 x ResNet-34, N = 64
+    from xrface import steps
+    from xrface.model import model_irse, resnet
+    n = int(os.environ.get("N", 64))
+    teacher = model_irse.IR_50([112, 112]).to(dev).eval()
+    student, assistant = resnet.ResNet_34().to(dev), resnet.ResNet_34().to(dev)
+    so = torch.optim.RMSprop(student.parameters(), lr=1e-4, weight_decay=1e-5)
+    ao = torch.optim.RMSprop(assistant.parameters(), lr=1e-4, weight_decay=1e-5)
+    xk = bench.synth_batch(n, dev, 0)[0]
+
+    def step():
+        so.zero_grad(set_to_none=True); ao.zero_grad(set_to_none=True)
+        steps.kd_step(teacher, student, assistant, xk, so, ao)
+
+
 # VARIANTS="name:knob=val,knob=val;..." ; special key: wb = ops wgrad_blocks
 variants = []
 for spec in os.environ.get("VARIANTS", "base:;wprio:5=1").split(";"):
