@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": 1}
 
 
 def set_compute_dtype(dtype):
@@ -100,13 +100,55 @@ def _direct_done(p):
         hook(p)
 
 
+# Weight gradients have no consumer inside backward (direct mode: they are accumulated into p.grad and first read by the
+# all-reduce / optimizer), so they can run on a side stream, concurrently with the dgrad -> norm-backward chain of the
+# main stream: their MFMA work fills the ramp-up / tail bubbles and the idle CUs of the main-stream kernels and overlaps
+# the HBM-bound elementwise passes.  The main stream re-joins at the end of the backward pass (autograd engine callback)
+# and before any gradient bucket is handed to RCCL.
+_side = {"stream": None, "dev": None, "pending": False, "cb": False}
+
+
+def join_side_stream():
+    """Make the current stream wait for the weight-gradient side stream (no-op when nothing is pending)."""
+    if _side["pending"]:
+        torch.cuda.current_stream(_side["dev"]).wait_stream(_side["stream"])
+        _side["pending"] = False
+
+
+def _join_cb():
+    _side["cb"] = False
+    join_side_stream()
+
+
 def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg, split, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
     """Weight gradient: sliced implicit GEMM into per-slice slabs, then sum + convert to the parameter layout
     (accumulating straight into ``w.grad`` when direct mode is on)."""
+    tgt = _direct(w)
+    if tgt is not None and _cfg["wgrad_stream"]:
+        dev = x.device
+        if _side["stream"] is None or _side["dev"] != dev:
+            _side["stream"], _side["dev"] = torch.cuda.Stream(dev), dev
+        side = _side["stream"]
+        side.wait_stream(torch.cuda.current_stream(dev))   # x, dy and the zeroed gradient buffer are ready
+        with torch.cuda.stream(side):
+            slabs = torch.empty((split, K, kg), dtype=torch.float32, device=dev)
+            ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
+                                   kg, split, stream())
+            lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, stream())
+        x.record_stream(side)    # the caching allocator must not hand these blocks out again before the side kernels ran
+        dy.record_stream(side)
+        _side["pending"] = True
+        if not _side["cb"]:
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_cb)
+                _side["cb"] = True
+            except RuntimeError:   # not inside a backward pass: join right away
+                join_side_stream()
+        _direct_done(w)
+        return None
     slabs = torch.empty((split, K, kg), dtype=torch.float32, device=x.device)
     ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg,
                            split, stream())
-    tgt = _direct(w)
     if tgt is not None:
         lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, stream())
         _direct_done(w)

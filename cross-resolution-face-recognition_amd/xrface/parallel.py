@@ -39,6 +39,7 @@ class FlatParams:
 
     def zero_grad(self):
         """One memset; .grad tensors stay allocated views (autograd accumulates in place)."""
+        ops.join_side_stream()
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
@@ -90,6 +91,7 @@ class BucketedAllReduce:
         self._works = []
 
     def _launch(self, b):
+        ops.join_side_stream()   # weight gradients computed on the side stream must have landed in the bucket
         lo, hi, _ = self.buckets[b]
         buf = self.flat.grad[lo:hi]
         if self.backend == "nccl":

@@ -138,3 +138,78 @@ def test_graphed_dropout_draws_fresh_masks():
         assert 0.5 < keep < 0.7
         seen.append(out.clone())
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2]) and not torch.equal(seen[2], seen[3])
+
+
+def test_side_stream_wgrad_matches_single_stream():
+    """FlatParams(direct=True): weight gradients computed on the side stream (overlapping the rest of backward) equal the
+    single-stream gradients; checked over several steps with recycled activation memory (allocator record_stream path)."""
+    import xrface
+    from xrface import ops, parallel
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model.model_irse import IR_SE_50
+
+    xrface.set_compute_dtype(torch.float32)
+    torch.manual_seed(11)
+    m1 = IR_SE_50([112, 112]).to(DEV).train()
+    m2 = copy.deepcopy(m1)
+    for m in (m1, m2):
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    f1, f2 = parallel.FlatParams(m1.parameters()), parallel.FlatParams(m2.parameters())
+    crit = CrossEntropyLoss()
+    y = torch.randint(0, 512, (6,), device=DEV)
+    old = ops._cfg["wgrad_stream"]
+    try:
+        for it in range(3):
+            x = _faces(6, 40 + it)
+            for flat, model, mode in ((f1, m1, 0), (f2, m2, 1)):
+                ops._cfg["wgrad_stream"] = mode
+                flat.zero_grad()
+                crit(model(x), y).backward()
+                junk = [torch.empty(1 << 22, device=DEV).normal_() for _ in range(8)]   # churn the allocator right after
+                del junk
+            torch.cuda.synchronize()
+            # bar = the single-stream path's own run-to-run spread on this tiny-batch train-mode network (fp32 atomics order
+            # amplified by BatchNorm: up to 5e-3, DESIGN.md section 3); a race would be orders of magnitude above it
+            assert _rel(f2.grad, f1.grad) < 1e-2, it
+            assert float(f1.grad.abs().max()) > 0
+    finally:
+        ops._cfg["wgrad_stream"] = old
+
+
+def test_side_stream_wgrad_inside_graph():
+    """The side stream forks from and re-joins the capturing stream, so a graphed step may use it."""
+    import xrface
+    from xrface import ops, parallel
+    from xrface.graph import GraphedStep
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model.resnet import ResNet_34
+
+    xrface.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(2)
+    model = ResNet_34().to(DEV).train()
+    flat = parallel.FlatParams(model.parameters())
+    opt = parallel.FusedSGD(flat, lr=0.01, momentum=0.9)
+    crit = CrossEntropyLoss()
+    y = torch.randint(0, 512, (8,), device=DEV)
+    loss_buf = torch.zeros((), device=DEV)
+    old = ops._cfg["wgrad_stream"]
+    ops._cfg["wgrad_stream"] = 1
+    try:
+        def step(x):
+            opt.zero_grad()
+            loss = crit(model(x)[0], y)
+            loss.backward()
+            opt.step()
+            loss_buf.copy_(loss.detach())
+            return loss_buf
+        x = _faces(8, 1)
+        gs = GraphedStep(step, [x], warmup=3)
+        first = float(gs(x))
+        for _ in range(20):
+            last = float(gs(x))
+        assert last == last and last < first     # still training on the fixed batch
+    finally:
+        ops._cfg["wgrad_stream"] = old
+        xrface.set_compute_dtype(torch.float32)
