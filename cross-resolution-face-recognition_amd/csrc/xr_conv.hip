@@ -1069,7 +1069,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __rest
 
 __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ dst, int A2, int taps, int B,
                                     int Bp, int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, int accumulate,
-                                    int nslices, int64_t slice_stride, int64_t total) {
+                                    int nslices, int64_t slice_stride, int64_t total, int spg) {
+  // blockIdx.y selects a group of `spg` slices; with more than one group the groups meet in dst by atomicAdd
+  const int s_beg = blockIdx.y * spg;
+  const int s_end = (s_beg + spg < nslices) ? s_beg + spg : nslices;
+  const bool atomic = gridDim.y > 1;
   // iterate over destination-meaningful elements (a, tap, b)
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i % B);
@@ -1078,10 +1082,19 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ packed, float* __r
     const int64_t a = r / taps;
     const int64_t a1 = a / A2, a2 = a - a1 * A2;
     const float* src = packed + a * Kg + (int64_t)tp * Bp + b;
-    float v = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) v += src[sl * slice_stride];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int sl = s_beg;
+    for (; sl + 3 < s_end; sl += 4) {  // four independent loads in flight
+      v0 += src[sl * slice_stride];
+      v1 += src[(sl + 1) * slice_stride];
+      v2 += src[(sl + 2) * slice_stride];
+      v3 += src[(sl + 3) * slice_stride];
+    }
+    for (; sl < s_end; ++sl) v0 += src[sl * slice_stride];
+    const float v = (v0 + v1) + (v2 + v3);
     float* d = dst + a1 * sa1 + a2 * sa2 + tp * st_ + b * sb;
-    *d = (accumulate & 1) ? (*d + v) : v;
+    if (atomic) atomicAdd(d, v);
+    else *d = (accumulate & 1) ? (*d + v) : v;
   }
 }
 
@@ -1420,7 +1433,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   XR_CHECK_ARG(packed && dst && nslices >= 1, "xr_unpack_wgrad: null pointer / nslices < 1");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Kg >= taps * Bp, "xr_unpack_wgrad: bad dims");
   const int64_t total = (int64_t)A1 * A2 * taps * B;
-  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 16 && taps <= 64 && A1 <= 65535) {
+  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 16 && taps <= 64 && A1 <= 65535 && B >= 32) {
     // wide transposes (Linear viewed as a 7x7 conv: 49 taps): LDS-tiled so both sides stay coalesced
     hipLaunchKernelGGL(unpack_fwdform_kernel, dim3(cdiv(B, 64), A1), dim3(256), (size_t)64 * taps * sizeof(float),
                        (hipStream_t)stream, packed, dst, taps, B, Bp, Kg, accumulate & 1, nslices, (int64_t)A1 * Kg);
@@ -1449,8 +1462,18 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   }
   int blocks = (int)((total + 255) / 256);
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, packed, dst, A2, taps, B, Bp,
-                     Kg, sa1, sa2, st_, sb, accumulate, nslices, (int64_t)A1 * A2 * Kg, total);
+  int groups = 1;
+  if (blocks < 512 && nslices > 16) groups = (nslices + 15) / 16;
+  const int spg = (nslices + groups - 1) / groups;
+  groups = (nslices + spg - 1) / spg;
+  if (groups > 1 && !(accumulate & 1)) {
+    if (hipMemsetAsync(dst, 0, (size_t)total * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+      xr_set_error("xr_unpack_wgrad: memset failed");
+      return XR_E_LAUNCH;
+    }
+  }
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(blocks, groups), dim3(256), 0, (hipStream_t)stream, packed, dst, A2, taps, B, Bp,
+                     Kg, sa1, sa2, st_, sb, accumulate, nslices, (int64_t)A1 * A2 * Kg, total, spg);
   XR_CHECK_LAUNCH("xr_unpack_wgrad");
   return XR_OK;
 }

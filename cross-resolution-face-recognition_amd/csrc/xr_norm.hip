@@ -282,7 +282,11 @@ __global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const floa
   const float ga = gamma ? gamma[c] : 1.f;
   float dg = 0.f, db = 0.f, da = 0.f;
   const size_t GC = (size_t)G * C;
-  for (int g = 0; g < G; ++g) {
+  // blockIdx.y owns a run of groups (InstanceNorm: G = batch size; one thread walking all of them made this the third
+  // most expensive kernel of the FHN step); the per-channel sums of the runs meet by atomics
+  const int gpb = (G + gridDim.y - 1) / gridDim.y;
+  const int g_beg = blockIdx.y * gpb, g_end = (g_beg + gpb < G) ? g_beg + gpb : G;
+  for (int g = g_beg; g < g_end; ++g) {
     const size_t i = (size_t)g * C + c;
     const float s_dz = red[i], s_dzx = red[GC + i];
     const float mu = mean[i], is = invstd[i];
@@ -297,9 +301,15 @@ __global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const floa
     db += s_dz;
     da += red[2 * GC + i];
   }
-  if (dgamma) dgamma[c] += dg;
-  if (dbeta) dbeta[c] += db;
-  if (dalpha) dalpha[c] += da;
+  if (gridDim.y > 1) {
+    if (dgamma) atomicAdd(dgamma + c, dg);
+    if (dbeta) atomicAdd(dbeta + c, db);
+    if (dalpha) atomicAdd(dalpha + c, da);
+  } else {
+    if (dgamma) dgamma[c] += dg;
+    if (dbeta) dbeta[c] += db;
+    if (dalpha) dalpha[c] += da;
+  }
 }
 
 // sums red[v][g][c] over g into out[c] (used for PReLU-only dalpha and bias gradients)
@@ -656,7 +666,8 @@ extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* s
 extern "C" int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, const float* invstd, float* coef,
                                   float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, void* stream) {
   XR_CHECK_ARG(red && mean && invstd && coef && G > 0 && rows > 0 && C > 0, "xr_norm_bwd_coeffs: bad arguments");
-  hipLaunchKernelGGL(norm_bwd_coeffs_kernel, dim3(cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, red, gamma, mean, invstd,
+  const int gy = G >= 8 ? (G < 64 ? G : 64) : 1;
+  hipLaunchKernelGGL(norm_bwd_coeffs_kernel, dim3(cdiv(C, 128), gy), dim3(128), 0, (hipStream_t)stream, red, gamma, mean, invstd,
                      coef, dgamma, dbeta, dalpha, G, rows, C);
   XR_CHECK_LAUNCH("xr_norm_bwd_coeffs");
   return XR_OK;

@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": 1}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1"))}
 
 
 def set_compute_dtype(dtype):
@@ -124,7 +124,9 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
     """Weight gradient: sliced implicit GEMM into per-slice slabs, then sum + convert to the parameter layout
     (accumulating straight into ``w.grad`` when direct mode is on)."""
     tgt = _direct(w)
-    if tgt is not None and _cfg["wgrad_stream"]:
+    # (not while a HIP graph is being captured: graphs stay single-stream -- a captured fork/join brought nothing at the
+    # small batch sizes graphs are for, and multi-stream graph teardown is the less-trodden path of the runtime)
+    if tgt is not None and _cfg["wgrad_stream"] and not _graph["capturing"]:
         dev = x.device
         if _side["stream"] is None or _side["dev"] != dev:
             _side["stream"], _side["dev"] = torch.cuda.Stream(dev), dev
@@ -468,10 +470,12 @@ class _ConvTranspose2d(Function):
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
                               kg, Cp, None, 0, None, None, None, 1, stream())
         if ctx.needs_input_grad[1]:
-            # dw[ci][co][r][s] = sum_m dy[m][co] * x[gather_T(m, r, s)][ci]: rows = co, cols = (tap, ci)
-            kg = kg_of(R * S, Cp)
-            dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1, Kp, kg,
-                        _wgrad_split(N * Ho * Wo, Cout, kg), Cout, 1, R * S, Cin, Cp, R * S, 0, 1, Cout * R * S)
+            # dw[ci][co][r][s] = sum_{n,hi,wi} x[n,hi,wi,ci] * dy[n, hi*s - p + r, wi*s - p + s', co]: the weight gradient of an
+            # ordinary strided convolution whose input is dy and whose output gradient is x -- rows = ci, cols = (tap, co),
+            # forward gather (the fast incremental-cursor path) instead of a transposed gather of x
+            kg = kg_of(R * S, Kp)
+            dw = _wgrad(w, dy, x, N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0, Cp, kg,
+                        _wgrad_split(N * H * W, Cin, kg), Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, Cout))
         return dx, dw, db, None, None, None
