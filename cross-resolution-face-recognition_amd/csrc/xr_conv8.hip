@@ -394,7 +394,9 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   float dal[8], alv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) dal[e] = 0.f, alv[e] = 0.f;
-  if (ep && ncol < p.K) ld8(p.ep_alpha + ncol, alv);
+  bf16_t* __restrict__ out2 = reinterpret_cast<bf16_t*>(p.ep2_out);
+  const bool ep2 = p.ep2_out != nullptr;
+  if ((ep || ep2) && ncol < p.K) ld8(p.ep_alpha + ncol, alv);
 #pragma unroll 4
   for (int it = 0; it < WV / 8; ++it) {
     const int row = it * 8 + l8;
@@ -415,6 +417,13 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
       st8(dp, o);
     } else {
       *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+      if (ep2) {  // second output: PReLU of the value just produced (what the next convolution consumes)
+        float d[8], o[8];
+        ld8(sp, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = d[e] > 0.f ? d[e] : d[e] * alv[e];
+        st8(out2 + (size_t)m * p.ldo + ncol, o);
+      }
     }
   }
   if (ep) {

@@ -42,6 +42,8 @@ struct IgemmP {
   const float* ep_alpha;
   float* ep_dalpha;   // [ep_spread][K]; row tile i adds into row i % ep_spread (spreads the hot atomic lines)
   int ep_spread;
+  // fused PReLU forward (second output): out2 = prelu(out, ep_alpha), laid out like `out`; exclusive with ep_src
+  void* ep2_out;
   int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
 };
 

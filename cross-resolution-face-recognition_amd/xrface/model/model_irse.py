@@ -65,9 +65,9 @@ class bottleneck_IR(Module):
     def _conv_prelu_conv(self, b1):
         """(BN output) -> conv3x3 -> PReLU -> conv3x3(stride); the PReLU backward rides in the second conv's dgrad epilogue."""
         rl = self.res_layer
-        y1 = rl[1].f(b1)
-        c2 = rl[3]
-        return ops.prelu_conv2d(y1, rl[2].weight, c2.weight, c2.stride[0], c2.padding[0])
+        c1, c2 = rl[1], rl[3]
+        y1, p1 = ops.conv2d_prelu(b1, c1.weight, rl[2].weight, c1.bias, c1.stride[0], c1.padding[0])  # PReLU out of the epilogue
+        return ops.prelu_conv2d(y1, rl[2].weight, c2.weight, c2.stride[0], c2.padding[0], p1)
 
     def _shortcut(self, x):
         if isinstance(self.shortcut_layer, Sequential):

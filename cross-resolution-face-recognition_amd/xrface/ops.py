@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1"))}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1}
 
 
 def set_compute_dtype(dtype):
@@ -383,7 +383,7 @@ class _Conv2d(Function):
     """aten::conv2d replacement (weight [K][C][R][S] fp32 Parameter; x NHWC buffer)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad):
+    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None):
         _need_cuda(x)
         x = _c(x)
         N, H, W, Cp = x.shape
@@ -394,18 +394,31 @@ class _Conv2d(Function):
         Kp = r8(K)
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
+        # prelu_alpha: also emit p = prelu(y, alpha) from the epilogue (second, non-differentiable output): the activation
+        # pass of conv -> PReLU -> conv disappears; its backward still rides in the next conv's dgrad epilogue
+        p2 = al = None
+        if prelu_alpha is not None and K % 8 == 0 and _cfg["fuse_prelu"]:
+            al = _c(prelu_alpha.detach().float())
+            p2 = torch.empty_like(y)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, None, None, None, 1, stream())
+                          kg, Kp, None, 0, None, ptr(al), None, 1, ptr(p2), stream())
         if pe is not None:
             pe.record()
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
+        if prelu_alpha is not None:
+            if p2 is None:
+                p2 = torch.empty_like(y)
+                al = _c(prelu_alpha.detach().float())
+                lib.xr_affine_act(dt(y), ptr(y), None, None, None, ptr(al), ACT_PRELU, ptr(p2), 1, N * Ho * Wo, Kp, 0, stream())
+            ctx.mark_non_differentiable(p2)
+            return y, p2
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dp2=None):
         x, w = ctx.saved_tensors
         stride, pad, has_b = ctx.geom
         dy = _c(dy)
@@ -419,14 +432,14 @@ class _Conv2d(Function):
             pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, None, 0, None, None, None, 1, stream())
+                              kg, Cp, None, 0, None, None, None, 1, None, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class _ConvTranspose2d(Function):
@@ -446,7 +459,7 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
-                          kg, Kp, None, 0, None, None, None, 1, stream())
+                          kg, Kp, None, 0, None, None, None, 1, None, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -468,7 +481,7 @@ class _ConvTranspose2d(Function):
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
-                              kg, Cp, None, 0, None, None, None, 1, stream())
+                              kg, Cp, None, 0, None, None, None, 1, None, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_{n,hi,wi} x[n,hi,wi,ci] * dy[n, hi*s - p + r, wi*s - p + s', co]: the weight gradient of an
             # ordinary strided convolution whose input is dy and whose output gradient is x -- rows = ci, cols = (tap, co),
@@ -500,11 +513,11 @@ class _LinearNHWC(Function):
         split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None,
                               stream())
             lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None,
                               stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -526,7 +539,7 @@ class _LinearNHWC(Function):
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
-                              HW * C, None, 0, None, None, None, 1, stream())
+                              HW * C, None, 0, None, None, None, 1, None, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
             dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
@@ -540,21 +553,22 @@ class _PreluConv2d(Function):
     backward fuses the PReLU backward into the input-gradient epilogue (no d_prelu round trip through HBM)."""
 
     @staticmethod
-    def forward(ctx, y1, alpha, w, stride, pad):
+    def forward(ctx, y1, alpha, w, stride, pad, p1=None):
         y1 = _c(y1)
         N, H, W, Cp = y1.shape
         K, C, R, S = w.shape
         assert C == Cp and C % 8 == 0
         al = _c(alpha.detach().float())
-        p1 = torch.empty_like(y1)
-        lib.xr_affine_act(dt(y1), ptr(y1), None, None, None, ptr(al), ACT_PRELU, ptr(p1), 1, N * H * W, C, 0, stream())
+        if p1 is None:   # (else: prelu(y1) already came out of the producing convolution's epilogue)
+            p1 = torch.empty_like(y1)
+            lib.xr_affine_act(dt(y1), ptr(y1), None, None, None, ptr(al), ACT_PRELU, ptr(p1), 1, N * H * W, C, 0, stream())
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         pk, kg = _packed(w, "fwd", y1.dtype, K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         Kp = r8(K)
         y2 = torch.empty((N, Ho, Wo, Kp), dtype=y1.dtype, device=y1.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
-                          None, None, None, 1, stream())
+                          None, None, None, 1, None, stream())
         if pe is not None:
             pe.record()
         ctx.save_for_backward(y1, p1, w, al)
@@ -588,7 +602,7 @@ class _PreluConv2d(Function):
             pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
             lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
-                              0, ptr(y1), ptr(al), ptr(dal_s), sp, stream())
+                              0, ptr(y1), ptr(al), ptr(dal_s), sp, None, stream())
             if sp > 1:
                 lib.xr_reduce_groups(ptr(dal_s), ptr(dal), 1, sp, C, 1 if t_a is not None else 0, stream())
             if t_a is not None:
@@ -599,11 +613,16 @@ class _PreluConv2d(Function):
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, p1, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
-        return dy1, dalpha, dw, None, None
+        return dy1, dalpha, dw, None, None, None
 
 
-def prelu_conv2d(y1, alpha, w, stride=1, pad=0):
-    return _PreluConv2d.apply(y1, alpha, w, stride, pad)
+def prelu_conv2d(y1, alpha, w, stride=1, pad=0, p1=None):
+    return _PreluConv2d.apply(y1, alpha, w, stride, pad, p1)
+
+
+def conv2d_prelu(x, w, alpha, b=None, stride=1, pad=0):
+    """(y, prelu(y, alpha)) with the activation produced by the convolution's epilogue; pass both to prelu_conv2d."""
+    return _Conv2d.apply(x, w, b, stride, pad, alpha)
 
 
 def conv2d(x, w, b=None, stride=1, pad=0):
