@@ -96,7 +96,6 @@ typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 // lane-linear, so the XOR swizzle is applied to the SOURCE chunk each lane fetches.
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT>
 __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2 : 4) : 1) void igemm_kernel(IgemmP p) {
-  const bool g_prio = p.prio != 0;
   constexpr int NBUF = DMA ? DMA : 1;
   static_assert(DMA == 0 || (FAST && MODE == 0), "DMA staging needs the FAST bf16 path");
   static_assert(BKT == 64 || (BKT == 32 && DMA != 0), "32-element stages exist for the DMA path only");
@@ -396,12 +395,12 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
 #pragma unroll
         for (int s = 0; s < NS; ++s) fb[j][s] = *reinterpret_cast<const bf16x8_t*>(sB + s * BN * ROWB + off);
       }
-      if (g_prio) __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(1);   // unconditional: a run-time switch here compiled to a scalar branch per MFMA group
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
-      if (g_prio) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
     }
   };
 
@@ -936,12 +935,12 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
           fb[j][s] = DMA ? tr_frag_sw<PX>(sX, ks * 16, wc0 + j * 32, lane) : tr_frag(sX + s * BP * PX, PX, ks * 16, wc0 + j * 32, lane);
-      if (p.prio) __builtin_amdgcn_s_setprio(1);
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma_split<NS>(fa[i], fb[j], acc[i][j]);
-      if (p.prio) __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(0);
     }
   };
 

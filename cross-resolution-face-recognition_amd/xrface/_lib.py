@@ -14,7 +14,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxrface.so")
+LIB_PATH = os.environ.get("XR_LIB") or os.path.join(_HERE, "libxrface.so")   # XR_LIB: A/B a differently built library
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "xrface.h"))
 
 XR_BF16, XR_F32 = 0, 1
