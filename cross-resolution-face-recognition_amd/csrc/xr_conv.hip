@@ -189,14 +189,19 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
         aw = fdiv(p.fd_st, aw - s0);
       }
       a_off[i] = ((a_nb[i] + ah * p.W + aw) * p.C + cc * 8) * ESZ;
-      unsigned lo = 0;
-      int ti = 0;
-      for (int rr = 0; rr < nrw; ++rr)
-        for (int ss = 0; ss < nsw; ++ss, ++ti) {
-          const int y = TR ? ah - rr : ah + rr, x = TR ? aw - ss : aw + ss;
-          const bool ok = a_valid[i] && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-          if (ok) lo |= 1u << ti;
-        }
+      // tap (rr, ss) is inside the image iff its row and its column are: build the column mask once and replicate it
+      // for every valid tap row (R + S comparisons per gathered row instead of R * S -- the prologue is a visible share
+      // of the instruction stream on the nine-stage 64-channel layers)
+      unsigned xm = 0, lo = 0;
+      for (int ss = 0; ss < nsw; ++ss) {
+        const int x = TR ? aw - ss : aw + ss;
+        if ((unsigned)x < (unsigned)p.W) xm |= 1u << ss;
+      }
+      if (!a_valid[i]) xm = 0;
+      for (int rr = 0; rr < nrw; ++rr) {
+        const int y = TR ? ah - rr : ah + rr;
+        if ((unsigned)y < (unsigned)p.H) lo |= xm << (rr * nsw);
+      }
       a_mlo[i] = lo;
     }
 #pragma unroll

@@ -108,13 +108,16 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
       decode_pixel<TR>(rel < WV ? tile_m * BMV + wrow * WV + rel : p.M, p.M, p.fd_howo, p.fd_wo, HW, p.stride, p.pad, valid, nb,
                        oh0, ow0);
       a_off[mi][i] = ((nb + oh0 * p.W + ow0) * p.C + cc * 8) * 2;
-      unsigned m = 0;
-      int ti = 0;
-      for (int rr = 0; rr < p.R; ++rr)
-        for (int ss = 0; ss < p.S; ++ss, ++ti) {
-          const int y = TR ? oh0 - rr : oh0 + rr, x = TR ? ow0 - ss : ow0 + ss;
-          if (valid && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) m |= 1u << ti;
-        }
+      unsigned xm = 0, m = 0;   // separable validity: column mask replicated for every valid tap row
+      for (int ss = 0; ss < p.S; ++ss) {
+        const int x = TR ? ow0 - ss : ow0 + ss;
+        if ((unsigned)x < (unsigned)p.W) xm |= 1u << ss;
+      }
+      if (!valid) xm = 0;
+      for (int rr = 0; rr < p.R; ++rr) {
+        const int y = TR ? oh0 - rr : oh0 + rr;
+        if ((unsigned)y < (unsigned)p.H) m |= xm << (rr * p.S);
+      }
       a_msk[mi][i] = m;
     }
 #pragma unroll
