@@ -657,6 +657,7 @@ struct WgradP {
   int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c, tiles_all;
   FastDiv fd_howo, fd_wo;
   int a64, b64, c64;            // 64 pixels = a64 images + b64 rows + c64 columns (per-step cursor advance)
+  int d64, dwrap_w, dwrap_h;    // byte deltas of the gather offset: per 64-pixel advance, per column wrap, per row wrap
   int prio;                     // raise wave priority around the MFMA clusters (tuning knob 5)
   unsigned in_bytes, dy_bytes;  // buffer-descriptor extents (FAST path)
 };
@@ -743,6 +744,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   const int cch = j0 - tap * p.C;
   const int tr_ = tap / p.S, ts_ = tap - tr_ * p.S;
   const bool col_ok = (tap < p.R * p.S) && (j0 < p.Kg);
+  // cursor constants: per-stage advance of the input row / column, wrap limits of this thread's tap, wrap spans
+  const int adv_w = p.c64 * p.stride, adv_h = p.b64 * p.stride, span_w = p.Wo * p.stride, span_h = p.Ho * p.stride;
+  const int wlim = span_w + ts_ - p.pad, hlim = span_h + tr_ - p.pad;
   const bool ycol_ok = (r0 + ych * 8) < p.ldy;
 
   float y_f[MODE ? NY : 1][8], x_f[MODE ? NX : 1][8];
@@ -750,7 +754,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 
   // ---- FAST path state
   constexpr int ESZ = (int)sizeof(in_t);
-  int xn[FAST ? NX : 1], xh[FAST ? NX : 1], xw[FAST ? NX : 1];
+  // per-slot gather cursor kept in the form the load needs: byte offset of the tap's input pixel (xl), its input row /
+  // column (xhv, xwv) for the bounds test; a 64-pixel advance is three adds plus two conditional wrap corrections with
+  // launch-uniform deltas (was: re-deriving the address from (n, ho, wo) with two multiplies per slot and stage)
+  int xl[FAST ? NX : 1], xhv[FAST ? NX : 1], xwv[FAST ? NX : 1];
   unsigned y_base[FAST ? NY : 1];
   __amdgpu_buffer_rsrc_t rsX, rsY;
   if constexpr (FAST) {
@@ -768,7 +775,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
         const int n = fdiv(p.fd_howo, m);
         const int rem = m - n * (int)p.fd_howo.d;
         const int ho = fdiv(p.fd_wo, rem);
-        xn[i] = n; xh[i] = ho; xw[i] = rem - ho * (int)p.fd_wo.d;
+        const int wo = rem - ho * (int)p.fd_wo.d;
+        xhv[i] = ho * p.stride - p.pad + tr_;
+        xwv[i] = wo * p.stride - p.pad + ts_;
+        xl[i] = (((n * p.H + xhv[i]) * p.W + xwv[i]) * p.C + cch) * ESZ;
       }
     }
   };
@@ -791,9 +801,9 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int hi = xh[i] * p.stride - p.pad + tr_, wi = xw[i] * p.stride - p.pad + ts_;
-      const bool ok = col_ok && xn[i] < p.N && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      const unsigned voff = ok ? (unsigned)((((xn[i] * p.H + hi) * p.W + wi) * p.C + cch) * ESZ) : XR_OOR;
+      const bool ok = col_ok && mbase + xrow0 + (NT / CRX) * i < p.M && (unsigned)xhv[i] < (unsigned)p.H &&
+                      (unsigned)xwv[i] < (unsigned)p.W;
+      const unsigned voff = ok ? (unsigned)xl[i] : XR_OOR;
       if constexpr (MODE == 1) {
         const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff, 0, 0);
         const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + 16u, 0, 0);
@@ -804,10 +814,10 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
         x_u[i] = make_uint4(u[0], u[1], u[2], u[3]);
       }
       // advance this slot's pixel cursor by 64 pixels
-      int w = xw[i] + p.c64, h = xh[i] + p.b64, n = xn[i] + p.a64;
-      if (w >= p.Wo) { w -= p.Wo; ++h; }
-      if (h >= p.Ho) { h -= p.Ho; ++n; }
-      xw[i] = w; xh[i] = h; xn[i] = n;
+      int wv = xwv[i] + adv_w, hv = xhv[i] + adv_h, l = xl[i] + p.d64;
+      if (wv >= wlim) { wv -= span_w; hv += p.stride; l += p.dwrap_w; }
+      if (hv >= hlim) { hv -= span_h; l += p.dwrap_h; }
+      xwv[i] = wv; xhv[i] = hv; xl[i] = l;
     }
   };
 
@@ -828,14 +838,14 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       }
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
-        const int hi = xh[i] * p.stride - p.pad + tr_, wi = xw[i] * p.stride - p.pad + ts_;
-        const bool ok = col_ok && xn[i] < p.N && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const unsigned voff = ok ? (unsigned)((((xn[i] * p.H + hi) * p.W + wi) * p.C + cch) * ESZ) : XR_OOR;
+        const bool ok = col_ok && mbase + xrow0 + (NT / CRX) * i < p.M && (unsigned)xhv[i] < (unsigned)p.H &&
+                        (unsigned)xwv[i] < (unsigned)p.W;
+        const unsigned voff = ok ? (unsigned)xl[i] : XR_OOR;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + (wv * (64 / CRX) + (NT / CRX) * i) * PX), 16, voff, 0, 0, 0);
-        int w = xw[i] + p.c64, h = xh[i] + p.b64, n = xn[i] + p.a64;
-        if (w >= p.Wo) { w -= p.Wo; ++h; }
-        if (h >= p.Ho) { h -= p.Ho; ++n; }
-        xw[i] = w; xh[i] = h; xn[i] = n;
+        int wv = xwv[i] + adv_w, hv = xhv[i] + adv_h, l = xl[i] + p.d64;
+        if (wv >= wlim) { wv -= span_w; hv += p.stride; l += p.dwrap_w; }
+        if (hv >= hlim) { hv -= span_h; l += p.dwrap_h; }
+        xwv[i] = wv; xhv[i] = hv; xl[i] = l;
       }
 #else
       (void)step; (void)buf;
@@ -1017,6 +1027,9 @@ int launch_wgrad(WgradP& p, int split, hipStream_t st) {
   p.a64 = 64 / howo;
   p.b64 = (64 % howo) / p.Wo;
   p.c64 = (64 % howo) % p.Wo;
+  p.d64 = (int)(((long long)p.a64 * p.H * p.W + (long long)p.b64 * p.stride * p.W + (long long)p.c64 * p.stride) * p.C * esz);
+  p.dwrap_w = (int)(((long long)p.stride * p.W - (long long)p.Wo * p.stride) * p.C * esz);
+  p.dwrap_h = (int)(((long long)p.H * p.W - (long long)p.Ho * p.stride * p.W) * p.C * esz);
   if constexpr (!TR) {
     if constexpr (MODE == 0) {
       // LDS-DMA staging: measured per layer shape (tools/conv_bench.py) -- pays on the stride-1 gathers with >= 128 input
@@ -1542,7 +1555,7 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
                ldy);
   XR_CHECK_ARG(Kg % 64 == 0 && Kg >= R * S * C, "xr_conv_wgrad: bad Kg=%d", Kg);
   XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
-  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, g_tune[5], 0, 0};
+  WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0, 0, g_tune[5], 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool tall = K > 64;
   if (dtype == XR_BF16) {
