@@ -87,6 +87,10 @@ class ResNet(Module):
         return Sequential(*layers)
 
     def f(self, buf):
+        with xnn.batched_bn_counters(self):   # one multi-tensor add instead of one counter kernel per BatchNorm
+            return self._f(buf)
+
+    def _f(self, buf):
         y = self.bn1.f(self.conv1.f(buf), act="relu")
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
