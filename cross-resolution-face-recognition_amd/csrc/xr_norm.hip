@@ -181,6 +181,50 @@ __global__ void norm_finalize_kernel(const float* __restrict__ sums, const float
   }
 }
 
+// BatchNorm with partial sums: sums is [2][fold][C] (per-image or pseudo-group partials of ONE statistics group); fold them and
+// finalize in the same launch -- (replaces xr_reduce_groups + xr_norm_finalize)
+__global__ __launch_bounds__(256) void norm_finalize_fold_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ mean,
+                                                                 float* __restrict__ invstd, float* __restrict__ scale,
+                                                                 float* __restrict__ shift, float* __restrict__ rmean,
+                                                                 float* __restrict__ rvar, int fold, int rows, int C, float eps,
+                                                                 float momentum) {
+  // 256 threads = 8 channels x 32 partial lanes: the fold is a latency chain, so it is kept short (fold / 32 loads per lane)
+  __shared__ float part[2][32][8];
+  const int cl = threadIdx.x & 7, fl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C)
+    for (int f = fl; f < fold; f += 32) {
+      s0 += sums[(size_t)f * C + c];
+      s1 += sums[((size_t)fold + f) * C + c];
+    }
+  part[0][fl][cl] = s0;
+  part[1][fl][cl] = s1;
+  __syncthreads();
+  if (fl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 32; ++k) {
+    s0 += part[0][k][cl];
+    s1 += part[1][k][cl];
+  }
+  const float n = (float)rows;
+  const float mu = s0 / n;
+  float var = s1 / n - mu * mu;
+  var = var > 0.f ? var : 0.f;
+  const float is = rsqrtf(var + eps);
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  if (mean) mean[c] = mu;
+  if (invstd) invstd[c] = is;
+  scale[c] = ga * is;
+  shift[c] = be - mu * ga * is;
+  if (rmean != nullptr) {
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+    const float unb = rows > 1 ? var * n / (n - 1.f) : var;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
 __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar,
                                       float* scale, float* shift, int C, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,21 +357,22 @@ __global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const floa
 }
 
 // sums red[v][g][c] over g into out[c] (used for PReLU-only dalpha and bias gradients)
-// blockIdx.y = vector v: out[v][c] (+)= sum_g red[v][g][c]; 256 threads = (C-chunk of 32) x 8 group-lanes
+// blockIdx.y = vector v: out[v][c] (+)= sum_g red[v][g][c]; 256 threads = 8 channels x 32 group lanes -- the fold is a
+// latency chain of G / lanes dependent loads, so it gets many lanes rather than wide rows (the data is a few hundred KB in L2)
 __global__ void reduce_groups_kernel(const float* __restrict__ red, float* __restrict__ out, int G, int C, int accumulate) {
-  __shared__ float part[8][32];
-  const int cl = threadIdx.x & 31, gl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  __shared__ float part[32][8];
+  const int cl = threadIdx.x & 7, gl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
   const float* base = red + (size_t)blockIdx.y * G * C;
   float s = 0.f;
   if (c < C)
-    for (int g = gl; g < G; g += 8) s += base[(size_t)g * C + c];
+    for (int g = gl; g < G; g += 32) s += base[(size_t)g * C + c];
   part[gl][cl] = s;
   __syncthreads();
   if (gl == 0 && c < C) {
     float tot = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += part[k][cl];
+    for (int k = 0; k < 32; ++k) tot += part[k][cl];
     float* o = out + (size_t)blockIdx.y * C + c;
     *o = accumulate ? *o + tot : tot;
   }
@@ -532,40 +577,59 @@ __global__ __launch_bounds__(NT) void bnse_bwd_coeffs_kernel(const float* __rest
                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
                                                              const float* __restrict__ a_eval, float* __restrict__ coef,
                                                              float* dgamma, float* dbeta, int N, int C, float hw, int train) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  if (c >= C) return;
+  // 256 threads = 8 channels x 32 image lanes (32-B row segments, short dependent-load chains: N / 32 iterations)
+  __shared__ float part[2][32][8];
+  __shared__ float cf[3][8];
+  const int cl = threadIdx.x & 7, lane = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  const bool live = c < C;
   float t1 = 0.f, t2 = 0.f;
-  for (int n = lane; n < N; n += 64) {
-    const size_t i = (size_t)n * C + c;
-    t1 += s[i] * S1[i] + hw * dp[i];
-    t2 += s[i] * S2[i] + dp[i] * sum_y[i];
+  if (live)
+    for (int n = lane; n < N; n += 32) {
+      const size_t i = (size_t)n * C + c;
+      t1 += s[i] * S1[i] + hw * dp[i];
+      t2 += s[i] * S2[i] + dp[i] * sum_y[i];
+    }
+  part[0][lane][cl] = t1;
+  part[1][lane][cl] = t2;
+  __syncthreads();
+  float t2hat = 0.f;
+  if (lane == 0 && live) {
+    t1 = 0.f; t2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      t1 += part[0][k][cl];
+      t2 += part[1][k][cl];
+    }
+    const float ga = gamma ? gamma[c] : 1.f;
+    const float mu = mean[c], is = invstd[c];
+    t2hat = is * (t2 - mu * t1);
+    float Abn, Bbn, Cbn;
+    if (train) {
+      const float ntot = (float)N * hw;
+      const float m1 = t1 / ntot, m2 = t2hat / ntot;
+      Abn = ga * is;
+      Bbn = -ga * is * is * m2;
+      Cbn = -Abn * m1 - Bbn * mu;
+    } else {
+      Abn = a_eval[c];
+      Bbn = 0.f;
+      Cbn = 0.f;
+    }
+    cf[0][cl] = Abn; cf[1][cl] = Bbn; cf[2][cl] = Cbn;
   }
-  t1 = wave_sum(t1);
-  t2 = wave_sum(t2);
-  const float ga = gamma ? gamma[c] : 1.f;
-  const float mu = mean[c], is = invstd[c];
-  const float t2hat = is * (t2 - mu * t1);
-  float Abn, Bbn, Cbn;
-  if (train) {
-    const float ntot = (float)N * hw;
-    const float m1 = t1 / ntot, m2 = t2hat / ntot;
-    Abn = ga * is;
-    Bbn = -ga * is * is * m2;
-    Cbn = -Abn * m1 - Bbn * mu;
-  } else {
-    Abn = a_eval[c];
-    Bbn = 0.f;
-    Cbn = 0.f;
+  __syncthreads();
+  if (live) {
+    const float Abn = cf[0][cl], Bbn = cf[1][cl], Cbn = cf[2][cl];
+    const size_t NC = (size_t)N * C;
+    for (int n = lane; n < N; n += 32) {
+      const size_t i = (size_t)n * C + c;
+      coef[i] = Abn * s[i];
+      coef[NC + i] = Bbn;
+      coef[2 * NC + i] = Abn * dp[i] + Cbn;
+    }
   }
-  const size_t NC = (size_t)N * C;
-  for (int n = lane; n < N; n += 64) {
-    const size_t i = (size_t)n * C + c;
-    coef[i] = Abn * s[i];
-    coef[NC + i] = Bbn;
-    coef[2 * NC + i] = Abn * dp[i] + Cbn;
-  }
-  if (lane == 0) {
+  if (lane == 0 && live) {
     if (dgamma) dgamma[c] += t2hat;
     if (dbeta) dbeta[c] += t1;
   }
@@ -617,9 +681,17 @@ extern "C" int xr_group_stats(int dtype, const void* x, float* sums, int G, int 
 
 extern "C" int xr_norm_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* invstd,
                                 float* scale, float* shift, float* running_mean, float* running_var, int G, int rows, int C,
-                                float eps, float momentum, void* stream) {
+                                float eps, float momentum, int fold, void* stream) {
   XR_CHECK_ARG(sums && scale && shift, "xr_norm_finalize: null pointer");
   XR_CHECK_ARG(G > 0 && rows > 0 && C > 0, "xr_norm_finalize: bad geometry");
+  XR_CHECK_ARG(fold <= 1 || G == 1, "xr_norm_finalize: partial sums (fold > 1) belong to one statistics group (G == 1)");
+  if (fold > 1) {
+    XR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "xr_norm_finalize: running stats must come in pairs");
+    hipLaunchKernelGGL(norm_finalize_fold_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, mean,
+                       invstd, scale, shift, running_mean, running_var, fold, rows, C, eps, momentum);
+    XR_CHECK_LAUNCH("xr_norm_finalize");
+    return XR_OK;
+  }
   XR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "xr_norm_finalize: running stats must come in pairs");
   XR_CHECK_ARG(running_mean == nullptr || G == 1, "xr_norm_finalize: running statistics need G == 1");
   const int n = G * C;
@@ -675,7 +747,7 @@ extern "C" int xr_norm_bwd_coeffs(const float* red, const float* gamma, const fl
 
 extern "C" int xr_reduce_groups(const float* red, float* out, int NV, int G, int C, int accumulate, void* stream) {
   XR_CHECK_ARG(red && out && NV > 0 && G > 0 && C > 0, "xr_reduce_groups: bad arguments");
-  hipLaunchKernelGGL(reduce_groups_kernel, dim3(cdiv(C, 32), NV), dim3(256), 0, (hipStream_t)stream, red, out, G, C, accumulate);
+  hipLaunchKernelGGL(reduce_groups_kernel, dim3(cdiv(C, 8), NV), dim3(256), 0, (hipStream_t)stream, red, out, G, C, accumulate);
   XR_CHECK_LAUNCH("xr_reduce_groups");
   return XR_OK;
 }
@@ -734,7 +806,7 @@ extern "C" int xr_bnse_bwd(const float* S1, const float* S2, const float* sum_y,
   hipLaunchKernelGGL(bnse_bwd_excite_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, S1, S2, a, b, w1,
                      w2, hidden, s, dpre2, dhid, dp, C, Cr, (float)HW);
   XR_CHECK_LAUNCH("xr_bnse_bwd(excite)");
-  hipLaunchKernelGGL(bnse_bwd_coeffs_kernel, dim3(cdiv(C, NT / 64)), dim3(NT), 0, (hipStream_t)stream, S1, S2, s, dp, sum_y,
+  hipLaunchKernelGGL(bnse_bwd_coeffs_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, S1, S2, s, dp, sum_y,
                      gamma, mean, invstd, a, coef, dgamma, dbeta, N, C, (float)HW, train);
   XR_CHECK_LAUNCH("xr_bnse_bwd(coeffs)");
   return XR_OK;

@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1}
 
 
 def set_compute_dtype(dtype):
@@ -671,8 +671,10 @@ class _NormAct(Function):
             if per_img:
                 sums_n = zeros_f32((2, pg, C), dev)
                 lib.xr_group_stats(dt(x), ptr(x), ptr(sums_n), pg, (N // pg) * H * W, C, stream())
-                sums = torch.empty((2, 1, C), **f32)
-                lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, pg, C, 0, stream())
+                sums = sums_n     # folded inside xr_norm_finalize
+                if not _cfg["fold_finalize"]:
+                    sums = torch.empty((2, 1, C), **f32)
+                    lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, pg, C, 0, stream())
             else:
                 sums = zeros_f32((2, G, C), dev)
                 lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
@@ -680,7 +682,8 @@ class _NormAct(Function):
             scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             upd = mode == "bn" and rmean is not None
             lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                 ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum, stream())
+                                 ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
+                                 pg if (per_img and _cfg["fold_finalize"]) else 1, stream())
         elif mode == "bn":
             scale, shift = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
             lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
@@ -857,10 +860,14 @@ class _BnSeAdd(Function):
         mean, invstd = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
         a, b = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
         if training:
-            sums = torch.empty((2, 1, C), **f32)
-            lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, N, C, 0, stream())
-            lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(a), ptr(b), ptr(rmean), ptr(rvar), 1,
-                                 N * HW, C, eps, momentum, stream())
+            if _cfg["fold_finalize"]:   # per-image sums folded over the batch in the same launch
+                lib.xr_norm_finalize(ptr(sums_n), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(a), ptr(b), ptr(rmean), ptr(rvar),
+                                     1, N * HW, C, eps, momentum, N, stream())
+            else:
+                sums = torch.empty((2, 1, C), **f32)
+                lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, N, C, 0, stream())
+                lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(a), ptr(b), ptr(rmean), ptr(rvar), 1,
+                                     N * HW, C, eps, momentum, 1, stream())
         else:
             lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(a), ptr(b), C, eps, stream())
             mean = rmean.detach().float().reshape(1, C)

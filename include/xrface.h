@@ -124,7 +124,9 @@ int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C
  * (1-momentum)*running + momentum*{mean, unbiased var}.  Outputs [G][C] fp32; gamma/beta are [C]. */
 int xr_norm_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* invstd,
                      float* scale, float* shift, float* running_mean, float* running_var, int G, int rows, int C,
-                     float eps, float momentum, void* stream);
+                     float eps, float momentum, int fold, void* stream);
+/* fold > 1 (G must be 1): `sums` is [2][fold][C], partial sums of the one statistics group (per-image or pseudo-group
+ * partials of a BatchNorm); they are added up inside the same launch.  fold <= 1: `sums` is [2][G][C]. */
 
 /* Eval-mode BatchNorm: scale/shift [C] from running statistics. */
 int xr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
