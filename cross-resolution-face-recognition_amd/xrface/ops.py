@@ -385,6 +385,7 @@ class _Conv2d(Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, prelu_alpha=None):
         _need_cuda(x)
+        ctx.set_materialize_grads(False)   # the non-differentiable PReLU output must not cost a zero-filled gradient tensor
         x = _c(x)
         N, H, W, Cp = x.shape
         K, C, R, S = w.shape
@@ -419,6 +420,8 @@ class _Conv2d(Function):
 
     @staticmethod
     def backward(ctx, dy, _dp2=None):
+        if dy is None:
+            return None, None, None, None, None, None
         x, w = ctx.saved_tensors
         stride, pad, has_b = ctx.geom
         dy = _c(dy)
