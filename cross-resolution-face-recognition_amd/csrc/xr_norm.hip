@@ -356,6 +356,48 @@ __global__ void norm_bwd_coeffs_kernel(const float* __restrict__ red, const floa
   }
 }
 
+// BatchNorm backward coefficients from PARTIAL reductions: red is [3][fold][C] (pseudo-group partials of the one statistics
+// group); fold + coefficients in one launch (replaces xr_reduce_groups + xr_norm_bwd_coeffs); 8 channels x 32 partial lanes
+__global__ __launch_bounds__(256) void norm_bwd_coeffs_fold_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                   float* __restrict__ coef, float* dgamma, float* dbeta,
+                                                                   float* dalpha, int fold, int rows, int C) {
+  __shared__ float part[3][32][8];
+  const int cl = threadIdx.x & 7, fl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  if (c < C)
+    for (int f = fl; f < fold; f += 32) {
+      s0 += red[(size_t)f * C + c];
+      s1 += red[((size_t)fold + f) * C + c];
+      s2 += red[((size_t)2 * fold + f) * C + c];
+    }
+  part[0][fl][cl] = s0;
+  part[1][fl][cl] = s1;
+  part[2][fl][cl] = s2;
+  __syncthreads();
+  if (fl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 1; k < 32; ++k) {
+    s0 += part[0][k][cl];
+    s1 += part[1][k][cl];
+    s2 += part[2][k][cl];
+  }
+  const float n = (float)rows;
+  const float ga = gamma ? gamma[c] : 1.f;
+  const float mu = mean[c], is = invstd[c];
+  const float s_dzxhat = is * (s1 - mu * s0);
+  const float m1 = s0 / n, m2 = s_dzxhat / n;
+  const float A = ga * is;
+  const float B = -ga * is * is * m2;
+  coef[c] = A;
+  coef[C + c] = B;
+  coef[2 * C + c] = -A * m1 - B * mu;
+  if (dgamma) dgamma[c] += s_dzxhat;
+  if (dbeta) dbeta[c] += s0;
+  if (dalpha) dalpha[c] += s2;
+}
+
 // sums red[v][g][c] over g into out[c] (used for PReLU-only dalpha and bias gradients)
 // blockIdx.y = vector v: out[v][c] (+)= sum_g red[v][g][c]; 256 threads = 8 channels x 32 group lanes -- the fold is a
 // latency chain of G / lanes dependent loads, so it gets many lanes rather than wide rows (the data is a few hundred KB in L2)
@@ -736,8 +778,15 @@ extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* s
 }
 
 extern "C" int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, const float* invstd, float* coef,
-                                  float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, void* stream) {
+                                  float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, int fold, void* stream) {
   XR_CHECK_ARG(red && mean && invstd && coef && G > 0 && rows > 0 && C > 0, "xr_norm_bwd_coeffs: bad arguments");
+  XR_CHECK_ARG(fold <= 1 || G == 1, "xr_norm_bwd_coeffs: partial reductions (fold > 1) belong to one statistics group (G == 1)");
+  if (fold > 1) {
+    hipLaunchKernelGGL(norm_bwd_coeffs_fold_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, red, gamma, mean, invstd,
+                       coef, dgamma, dbeta, dalpha, fold, rows, C);
+    XR_CHECK_LAUNCH("xr_norm_bwd_coeffs");
+    return XR_OK;
+  }
   const int gy = G >= 8 ? (G < 64 ? G : 64) : 1;
   hipLaunchKernelGGL(norm_bwd_coeffs_kernel, dim3(cdiv(C, 128), gy), dim3(128), 0, (hipStream_t)stream, red, gamma, mean, invstd,
                      coef, dgamma, dbeta, dalpha, G, rows, C);

@@ -720,8 +720,10 @@ class _NormAct(Function):
             red_n = zeros_f32((3, N_, C), x.device)
             lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red_n), N_, HW_,
                                          C, 0, stream())
-            red = torch.empty((3, 1, C), **f32)
-            lib.xr_reduce_groups(ptr(red_n), ptr(red), 3, N_, C, 0, stream())
+            red = red_n
+            if not stats:   # (with batch statistics the fold happens inside xr_norm_bwd_coeffs)
+                red = torch.empty((3, 1, C), **f32)
+                lib.xr_reduce_groups(ptr(red_n), ptr(red), 3, N_, C, 0, stream())
         else:
             red = zeros_f32((3, G, C), x.device)
             lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red), G, rows,
@@ -737,7 +739,7 @@ class _NormAct(Function):
             dbeta = (t_b if t_b is not None else zeros_f32((C,), x.device)) if has_b else None
             dalpha = (t_a if t_a is not None else zeros_f32((C,), x.device)) if has_a else None
             lib.xr_norm_bwd_coeffs(ptr(red), ptr(gm), ptr(mean), ptr(invstd), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dalpha),
-                                   G, rows, C, stream())
+                                   G, rows, C, N_ if per_img else 1, stream())
             if t_g is not None:
                 dgamma = None
                 _direct_done(p_g)

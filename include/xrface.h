@@ -151,7 +151,8 @@ int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* scale, const
  *   m1 = mean(dz), m2 = mean(dz*xhat);  dgamma[c] += sum_g sum dz*xhat ; dbeta[c] += sum_g sum dz;
  *   dalpha[c] += sum_g red[2].  coef = [3][G][C] fp32.  dgamma/dbeta/dalpha optional (accumulated). */
 int xr_norm_bwd_coeffs(const float* red, const float* gamma, const float* mean, const float* invstd, float* coef,
-                       float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, void* stream);
+                       float* dgamma, float* dbeta, float* dalpha, int G, int rows, int C, int fold, void* stream);
+/* fold > 1 (G must be 1): `red` is [3][fold][C] partial reductions of the one statistics group, added up in the same launch. */
 
 /* Backward, pass 2: dx = A*dz + B*x + C0  (coef NULL -> dx = dz*scale, or dz when scale NULL);
  * dres (optional) = dz. */
