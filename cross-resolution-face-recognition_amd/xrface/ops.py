@@ -120,6 +120,27 @@ def _join_cb():
     join_side_stream()
 
 
+def _side_launch(dev, fn, inputs):
+    """Run fn() (kernel launches whose only outputs are parameter gradients accumulated in place) on the side stream;
+    `inputs` are the tensors it reads.  Each call costs ~50-100 us of host time (stream switch, events): worth it for the
+    SE weight-gradient GEMMs, not for 5-us folds."""
+    if _side["stream"] is None or _side["dev"] != dev:
+        _side["stream"], _side["dev"] = torch.cuda.Stream(dev), dev
+    side = _side["stream"]
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        fn()
+    for t in inputs:
+        t.record_stream(side)
+    _side["pending"] = True
+    if not _side["cb"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_cb)
+            _side["cb"] = True
+        except RuntimeError:   # not inside a backward pass: join right away
+            join_side_stream()
+
+
 def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg, split, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
     """Weight gradient: sliced implicit GEMM into per-slice slabs, then sum + convert to the parameter layout
     (accumulating straight into ``w.grad`` when direct mode is on)."""
@@ -930,8 +951,14 @@ class _BnSeAdd(Function):
             t1, t2 = _direct(w1), _direct(w2)
             dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), dev)
             dw2 = t2 if t2 is not None else zeros_f32((C, Cr, 1, 1), dev)
-            lib.xr_small_atb(ptr(dhid), ptr(pooled), ptr(dw1), N, Cr, C, 1.0 / HW, 1, stream())
-            lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 1, stream())
+
+            def fc_grads():
+                lib.xr_small_atb(ptr(dhid), ptr(pooled), ptr(dw1), N, Cr, C, 1.0 / HW, 1, stream())
+                lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 1, stream())
+            if t1 is not None and t2 is not None and _cfg["wgrad_stream"] and not _graph["capturing"]:
+                _side_launch(dev, fc_grads, (dhid, pooled, dpre2, hidden))   # parameter gradients: off the critical path
+            else:
+                fc_grads()
             if t1 is not None:
                 dw1 = None
                 _direct_done(w1)
