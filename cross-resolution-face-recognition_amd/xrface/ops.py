@@ -105,7 +105,7 @@ def _direct_done(p):
 # main stream: their MFMA work fills the ramp-up / tail bubbles and the idle CUs of the main-stream kernels and overlaps
 # the HBM-bound elementwise passes.  The main stream re-joins at the end of the backward pass (autograd engine callback)
 # and before any gradient bucket is handed to RCCL.
-_side = {"stream": None, "dev": None, "pending": False, "cb": False}
+_side = {"stream": None, "dev": None, "ev": None, "pending": False, "cb": False}
 
 
 def join_side_stream():
@@ -120,17 +120,20 @@ def _join_cb():
     join_side_stream()
 
 
-def _side_launch(dev, fn, inputs):
-    """Run fn() (kernel launches whose only outputs are parameter gradients accumulated in place) on the side stream;
-    `inputs` are the tensors it reads.  Each call costs ~50-100 us of host time (stream switch, events): worth it for the
-    SE weight-gradient GEMMs, not for 5-us folds."""
+def _side_fork(dev):
+    """The side stream, made to wait for all work enqueued so far on the current stream (one reused event)."""
     if _side["stream"] is None or _side["dev"] != dev:
-        _side["stream"], _side["dev"] = torch.cuda.Stream(dev), dev
-    side = _side["stream"]
-    side.wait_stream(torch.cuda.current_stream(dev))
-    with torch.cuda.stream(side):
-        fn()
-    for t in inputs:
+        _side["stream"], _side["dev"], _side["ev"] = torch.cuda.Stream(dev), dev, torch.cuda.Event()
+    ev = _side["ev"]
+    ev.record()
+    _side["stream"].wait_event(ev)
+    return _side["stream"]
+
+
+def _side_done(side, tensors):
+    """Bookkeeping after side-stream launches: the caching allocator must not hand `tensors` out again before the side
+    kernels ran; the main stream re-joins at the end of the backward pass."""
+    for t in tensors:
         t.record_stream(side)
     _side["pending"] = True
     if not _side["cb"]:
@@ -149,24 +152,13 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
     # small batch sizes graphs are for, and multi-stream graph teardown is the less-trodden path of the runtime)
     if tgt is not None and _cfg["wgrad_stream"] and not _graph["capturing"]:
         dev = x.device
-        if _side["stream"] is None or _side["dev"] != dev:
-            _side["stream"], _side["dev"] = torch.cuda.Stream(dev), dev
-        side = _side["stream"]
-        side.wait_stream(torch.cuda.current_stream(dev))   # x, dy and the zeroed gradient buffer are ready
-        with torch.cuda.stream(side):
-            slabs = torch.empty((split, K, kg), dtype=torch.float32, device=dev)
-            ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
-                                   kg, split, stream())
-            lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, stream())
-        x.record_stream(side)    # the caching allocator must not hand these blocks out again before the side kernels ran
-        dy.record_stream(side)
-        _side["pending"] = True
-        if not _side["cb"]:
-            try:
-                torch.autograd.Variable._execution_engine.queue_callback(_join_cb)
-                _side["cb"] = True
-            except RuntimeError:   # not inside a backward pass: join right away
-                join_side_stream()
+        side = _side_fork(dev)     # side stream now waits for everything enqueued on the current stream (x, dy, zeroed grads)
+        sh = side.cuda_stream      # launch on the side stream by handle: no current-stream switch on the host
+        slabs = torch.empty((split, K, kg), dtype=torch.float32, device=dev)
+        ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
+                               kg, split, sh)
+        lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, sh)
+        _side_done(side, (x, dy, slabs))
         _direct_done(w)
         return None
     slabs = torch.empty((split, K, kg), dtype=torch.float32, device=x.device)
@@ -952,13 +944,13 @@ class _BnSeAdd(Function):
             dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), dev)
             dw2 = t2 if t2 is not None else zeros_f32((C, Cr, 1, 1), dev)
 
-            def fc_grads():
-                lib.xr_small_atb(ptr(dhid), ptr(pooled), ptr(dw1), N, Cr, C, 1.0 / HW, 1, stream())
-                lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 1, stream())
-            if t1 is not None and t2 is not None and _cfg["wgrad_stream"] and not _graph["capturing"]:
-                _side_launch(dev, fc_grads, (dhid, pooled, dpre2, hidden))   # parameter gradients: off the critical path
-            else:
-                fc_grads()
+            on_side = t1 is not None and t2 is not None and _cfg["wgrad_stream"] and not _graph["capturing"]
+            side = _side_fork(dev) if on_side else None      # parameter gradients: off the critical path
+            sh = side.cuda_stream if on_side else stream()
+            lib.xr_small_atb(ptr(dhid), ptr(pooled), ptr(dw1), N, Cr, C, 1.0 / HW, 1, sh)
+            lib.xr_small_atb(ptr(dpre2), ptr(hidden), ptr(dw2), N, C, Cr, 1.0, 1, sh)
+            if on_side:
+                _side_done(side, (dhid, pooled, dpre2, hidden))
             if t1 is not None:
                 dw1 = None
                 _direct_done(w1)
