@@ -409,36 +409,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
     }
   };
 
-  if constexpr (DMA == 3) {
-    // three-stage ring, two stages in flight: at the top of iteration k this wave waits only for ITS copies of stage k
-    // (counted vmcnt leaves the RA+RB newest = stage k+1 in flight), the raw barrier then makes every wave's stage k
-    // visible and proves stage k-1 fully consumed, so its buffer is handed to the DMA of stage k+2.  No vmcnt(0) and
-    // no __syncthreads() inside the loop (that would drain the in-flight stage).
-    if (kbeg < nk) dma_stage(0);
-    if (kbeg + 1 < nk) dma_stage(1);
-    int buf = 0;
-    for (int kk = kbeg; kk < nk; ++kk) {
-      if (kk + 1 < nk) {
-        if constexpr (RA + RB == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if constexpr (RA + RB == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if constexpr (RA + RB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (RA + RB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (RA + RB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        static_assert(RA + RB == 10 || RA + RB == 5 || RA + RB == 8 || RA + RB == 6 || RA + RB == 4 || RA + RB == 3,
-                      "unexpected DMA instruction count");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-      int nbuf = buf + 2;
-      if (nbuf >= 3) nbuf -= 3;
-      if (kk + 2 < nk) dma_stage(nbuf);
-      compute_stage(buf);
-      if (++buf == 3) buf = 0;
-    }
-    __syncthreads();
-  } else if constexpr (DMA == 2) {
+  if constexpr (DMA == 2) {
     // stage kk lives in buffer (kk-kbeg)&1.  The DMA of stage kk+1 into the other buffer is issued before the MFMAs
     // of stage kk; the barrier (hipcc drains vmcnt(0) in front of it because LDS-DMA is pending) then orders RAW
     // (next stage's reads) and WAR (the buffer just consumed becomes the next DMA target).
@@ -575,7 +546,7 @@ constexpr size_t igemm_smem() {
 }
 
 }  // namespace
-int g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] narrow tiles; [4] s_setprio around MFMA (igemm); [5] same for wgrad; [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
+int g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
 namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
@@ -596,9 +567,6 @@ int launch_igemm(IgemmP& p, hipStream_t st) {
     // LDS-DMA staging pays once the K loop is long enough to amortise the lower occupancy (2 x 32 KB stages per WG):
     // measured cross-over between the 128- and 256-channel 3x3 layers (18 vs 36 stages)
     const bool dma = g_tune[0] == 2 || (g_tune[0] == 3 && p.Kg / BK >= g_tune[6]);
-    if (fast && g_tune[0] == 4) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 3>(p, st);
-    if (fast && g_tune[0] == 5) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 2, 32>(p, st);
-    if (fast && g_tune[0] == 6) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 3, 32>(p, st);
     if (fast && dma) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 2>(p, st);
   }
   if (fast) return launch_igemm_f<MODE, BM, BN, WM, TR, true, 0>(p, st);
@@ -1537,7 +1505,6 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
   const bool wide = K > 64 && g_tune[3] == 0;
   if (dtype == XR_BF16) {
     if (wide) return transposed ? launch_igemm<0, 128, 128, 2, true>(p, st) : launch_igemm<0, 128, 128, 2, false>(p, st);
-    if (g_tune[3] == 2) return transposed ? launch_igemm<0, 256, 64, 4, true>(p, st) : launch_igemm<0, 256, 64, 4, false>(p, st);
     return transposed ? launch_igemm<0, 128, 64, 4, true>(p, st) : launch_igemm<0, 128, 64, 4, false>(p, st);
   }
   if (wide) return transposed ? launch_igemm<1, 128, 128, 2, true>(p, st) : launch_igemm<1, 128, 128, 2, false>(p, st);
