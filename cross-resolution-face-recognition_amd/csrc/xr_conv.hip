@@ -468,7 +468,11 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
   out_t* __restrict__ out = reinterpret_cast<out_t*>(p.out);
   constexpr int CPR = BN / 8;  // chunks per tile row
   const int Kw = (p.K + 7) & ~7;
-  const bool ep = p.ep_src != nullptr;   // requires K % 8 == 0 (checked by the host)
+  const bool bnr = p.ep_red != nullptr;                    // BatchNorm-backward partial sums (ep_src = BN input)
+  const bool ep = p.ep_src != nullptr && !bnr;   // PReLU backward; requires K % 8 == 0 (checked by the host)
+  float bs0[8], bs1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs0[e] = 0.f, bs1[e] = 0.f;
   const out_t* __restrict__ ep_src = reinterpret_cast<const out_t*>(p.ep_src);
   float dal[8], alv[8];
 #pragma unroll
@@ -504,6 +508,16 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
       st8(dp, o);
       continue;
     }
+    if (bnr) {  // sums of d and d * x per channel (d as rounded for the output tensor)
+      float d[8], xv[8];
+      ld8(sp, d);
+      ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        bs0[e] += d[e];
+        bs1[e] += d[e] * xv[e];
+      }
+    }
     if (ep2) {  // second output: PReLU of the value just produced (what the next convolution consumes)
       float d[8], o[8];
       ld8(sp, d);
@@ -532,6 +546,21 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
       float sum = 0.f;
       for (int r = 0; r < NT / CPR; ++r) sum += red[r * BN + c];
       if (n0 + c < p.K) atomicAdd(p.ep_dalpha + (size_t)(tile_m % p.ep_spread) * p.K + n0 + c, sum);
+    }
+  }
+  if (bnr) {  // same fold as dalpha, two vectors
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(t / CPR) * BN + (t % CPR) * 8 + e] = v ? bs1[e] : bs0[e];
+      __syncthreads();
+      for (int c = t; c < BN; c += NT) {
+        float sum = 0.f;
+        for (int r = 0; r < NT / CPR; ++r) sum += red[r * BN + c];
+        if (n0 + c < p.K) atomicAdd(p.ep_red + ((size_t)v * p.ep_spread + (tile_m % p.ep_spread)) * p.K + n0 + c, sum);
+      }
     }
   }
 }
@@ -1475,10 +1504,13 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
 extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                              int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
-                             const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, void* stream) {
+                             const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
-  XR_CHECK_ARG(ep_src == nullptr || (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
+  XR_CHECK_ARG(ep_src == nullptr || ep_red != nullptr ||
+                   (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
                "xr_conv_igemm: fused PReLU-backward epilogue needs alpha, dalpha, K %% 8 == 0, no bias, no split-K");
+  XR_CHECK_ARG(ep_red == nullptr || (ep_src && K % 8 == 0 && splitk_ws == nullptr && ep2_out == nullptr && out),
+               "xr_conv_igemm: fused BatchNorm-backward reduction needs the BatchNorm input (ep_src), K %% 8 == 0, no split-K");
   XR_CHECK_ARG(ep2_out == nullptr || (ep_alpha && ep_src == nullptr && K % 8 == 0 && splitk_ws == nullptr && out),
                "xr_conv_igemm: fused PReLU-forward output needs alpha, K %% 8 == 0, no PReLU-backward epilogue, no split-K");
   XR_CHECK_ARG((splitk_ws == nullptr) == (splitk <= 1), "xr_conv_igemm: split-K needs both a workspace and splitk > 1");
@@ -1499,7 +1531,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, ep_spread > 0 ? ep_spread : 1, ep2_out, g_tune[4]};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, ep_spread > 0 ? ep_spread : 1, ep2_out, ep_red, g_tune[4]};
   hipStream_t st = (hipStream_t)stream;
   if (xr_igemm8_eligible(p, dtype, transposed)) return xr_igemm8_launch(p, transposed, st);
   const bool wide = K > 64 && g_tune[3] == 0;

@@ -390,7 +390,11 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
   // wave-private image: the wave's own LDS writes are ordered before its reads by the compiler's lgkmcnt
   bf16_t* __restrict__ out = reinterpret_cast<bf16_t*>(p.out);
   const bf16_t* __restrict__ ep_src = reinterpret_cast<const bf16_t*>(p.ep_src);
-  const bool ep = p.ep_src != nullptr;
+  const bool bnr = p.ep_red != nullptr;               // BatchNorm-backward partial sums (ep_src = BN input)
+  const bool ep = p.ep_src != nullptr && !bnr;       // PReLU backward
+  float bs0[8], bs1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs0[e] = 0.f, bs1[e] = 0.f;
   const int ch = lane & 7;
   const int ncol = n0 + wc * 64 + ch * 8;
   const int Kw = (p.K + 7) & ~7;
@@ -420,6 +424,16 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
       st8(dp, o);
     } else {
       *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
+      if (bnr) {  // sums of d and d * x per channel (d as rounded for the output tensor)
+        float d[8], xv[8];
+        ld8(sp, d);
+        ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          bs0[e] += d[e];
+          bs1[e] += d[e] * xv[e];
+        }
+      }
       if (ep2) {  // second output: PReLU of the value just produced (what the next convolution consumes)
         float d[8], o[8];
         ld8(sp, d);
@@ -454,6 +468,34 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
 #pragma unroll
       for (int r = 0; r < WRN; ++r) sum += red[(r * WCN + cwc) * 64 + cc];
       if (n0 + c < p.K) atomicAdd(p.ep_dalpha + (size_t)(tile_m % p.ep_spread) * p.K + n0 + c, sum);
+    }
+  }
+  if (bnr) {  // same fold as dalpha (lanes -> wave rows through LDS -> one atomic per column and workgroup), two vectors
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v ? bs1[e] : bs0[e];
+        x += __shfl_xor(x, 8, 64);
+        x += __shfl_xor(x, 16, 64);
+        x += __shfl_xor(x, 32, 64);
+        f[e] = x;
+      }
+      __syncthreads();
+      if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wid * 64 + lane * 8 + e] = f[e];
+      }
+      __syncthreads();
+      for (int c = t; c < BN8; c += NT8) {
+        const int cwc = c >> 6, cc = c & 63;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < WRN; ++r) sum += red[(r * WCN + cwc) * 64 + cc];
+        if (n0 + c < p.K) atomicAdd(p.ep_red + ((size_t)v * p.ep_spread + (tile_m % p.ep_spread)) * p.K + n0 + c, sum);
+      }
     }
   }
 }

@@ -44,6 +44,9 @@ struct IgemmP {
   int ep_spread;
   // fused PReLU forward (second output): out2 = prelu(out, ep_alpha), laid out like `out`; exclusive with ep_src
   void* ep2_out;
+  // fused BatchNorm-backward reduction (the tensor being written is dL/d(bn output), ep_src = the BatchNorm's INPUT x):
+  // ep_red[0][row][c] += sum d, ep_red[1][row][c] += sum d * x with row = row tile % ep_spread; layout [3][ep_spread][K]
+  float* ep_red;
   int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
 };
 

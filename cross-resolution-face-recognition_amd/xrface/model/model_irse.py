@@ -62,11 +62,12 @@ class bottleneck_IR(Module):
             Conv2d(in_channel, depth, (3, 3), (1, 1), 1, bias=False), PReLU(depth),
             Conv2d(depth, depth, (3, 3), stride, 1, bias=False), BatchNorm2d(depth))
 
-    def _conv_prelu_conv(self, b1):
-        """(BN output) -> conv3x3 -> PReLU -> conv3x3(stride); the PReLU backward rides in the second conv's dgrad epilogue."""
+    def _conv_prelu_conv(self, b1, link=None):
+        """(BN output) -> conv3x3 -> PReLU -> conv3x3(stride); the PReLU backward rides in the second conv's dgrad epilogue,
+        the first BatchNorm's backward reductions in the first conv's (link)."""
         rl = self.res_layer
         c1, c2 = rl[1], rl[3]
-        y1, p1 = ops.conv2d_prelu(b1, c1.weight, rl[2].weight, c1.bias, c1.stride[0], c1.padding[0])  # PReLU out of the epilogue
+        y1, p1 = ops.conv2d_prelu(b1, c1.weight, rl[2].weight, c1.bias, c1.stride[0], c1.padding[0], link)  # PReLU out of the epilogue
         return ops.prelu_conv2d(y1, rl[2].weight, c2.weight, c2.stride[0], c2.padding[0], p1)
 
     def _shortcut(self, x):
@@ -77,9 +78,10 @@ class bottleneck_IR(Module):
     def f(self, x):
         # the block input feeds both the BN of the residual branch and the shortcut: route the shortcut through the
         # BN op's pass-through output so the two input gradients are summed inside its backward kernel
-        b1, xs = self.res_layer[0].f_pass(x)
+        link = ops.BnLink()
+        b1, xs = self.res_layer[0].f_pass(x, link)
         sc = self._shortcut(xs)
-        r = self._conv_prelu_conv(b1)
+        r = self._conv_prelu_conv(b1, link)
         return self.res_layer[4].f(r, res=sc)
 
     def forward(self, x):
@@ -99,9 +101,10 @@ class bottleneck_IR_SE(bottleneck_IR):
 
     def f(self, x):
         rl = self.res_layer
-        b1, xs = rl[0].f_pass(x)
+        link = ops.BnLink()
+        b1, xs = rl[0].f_pass(x, link)
         sc = self._shortcut(xs)
-        y2 = self._conv_prelu_conv(b1)
+        y2 = self._conv_prelu_conv(b1, link)
         return ops.bn_se_add(y2, rl[4], rl[5], sc)   # BatchNorm + SE + shortcut add in one elementwise pass
 
 

@@ -99,13 +99,14 @@ class _BNMixin:
                             mom, self.eps)
 
 
-    def f_pass(self, buf):
-        """(bn(buf), buf'): buf' aliases buf and carries the identity-branch gradient into this norm's backward."""
+    def f_pass(self, buf, link=None):
+        """(bn(buf), buf'): buf' aliases buf and carries the identity-branch gradient into this norm's backward.
+        link: an ops.BnLink shared with the one convolution that consumes bn(buf) (fused backward reduction)."""
         training = self.training or not self.track_running_stats
         self._count()
         mom = 0.1 if self.momentum is None else self.momentum
         return ops.norm_act_pass(buf, self.weight, self.bias, self.running_mean, self.running_var, "bn", None, training, mom,
-                                 self.eps)
+                                 self.eps, link if training else None)
 
 
 class BatchNorm2d(_BNMixin, nn.BatchNorm2d):

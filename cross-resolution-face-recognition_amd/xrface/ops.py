@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1}
 
 
 def set_compute_dtype(dtype):
@@ -396,7 +396,7 @@ class _Conv2d(Function):
     """aten::conv2d replacement (weight [K][C][R][S] fp32 Parameter; x NHWC buffer)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None):
+    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None, bn_link=None):
         _need_cuda(x)
         ctx.set_materialize_grads(False)   # the non-differentiable PReLU output must not cost a zero-filled gradient tensor
         x = _c(x)
@@ -416,12 +416,13 @@ class _Conv2d(Function):
             p2 = torch.empty_like(y)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, None, ptr(al), None, 1, ptr(p2), stream())
+                          kg, Kp, None, 0, None, ptr(al), None, 1, ptr(p2), None, stream())
         if pe is not None:
             pe.record()
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
+        ctx.bn_link = bn_link
         if prelu_alpha is not None:
             if p2 is None:
                 p2 = torch.empty_like(y)
@@ -434,7 +435,7 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy, _dp2=None):
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, w = ctx.saved_tensors
         stride, pad, has_b = ctx.geom
         dy = _c(dy)
@@ -447,15 +448,22 @@ class _Conv2d(Function):
         if ctx.needs_input_grad[0]:
             pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
+            link, red, sp_ = ctx.bn_link, None, 1
+            if link is not None and link.x is not None and _cfg["fuse_bn_reduce"] and C % 8 == 0 and link.x.shape == x.shape \
+                    and link.x.dtype == x.dtype:
+                sp_ = BnLink.SPREAD
+                red = zeros_f32((3, sp_, C), x.device)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, None, 0, None, None, None, 1, None, stream())
+                              kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red), stream())
+            if red is not None:
+                link.deliver(dx, red)
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class _ConvTranspose2d(Function):
@@ -475,7 +483,7 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
-                          kg, Kp, None, 0, None, None, None, 1, None, stream())
+                          kg, Kp, None, 0, None, None, None, 1, None, None, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -497,7 +505,7 @@ class _ConvTranspose2d(Function):
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
-                              kg, Cp, None, 0, None, None, None, 1, None, stream())
+                              kg, Cp, None, 0, None, None, None, 1, None, None, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_{n,hi,wi} x[n,hi,wi,ci] * dy[n, hi*s - p + r, wi*s - p + s', co]: the weight gradient of an
             # ordinary strided convolution whose input is dy and whose output gradient is x -- rows = ci, cols = (tap, co),
@@ -529,11 +537,11 @@ class _LinearNHWC(Function):
         split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None, None,
                               stream())
             lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None, None,
                               stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -555,7 +563,7 @@ class _LinearNHWC(Function):
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
-                              HW * C, None, 0, None, None, None, 1, None, stream())
+                              HW * C, None, 0, None, None, None, 1, None, None, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
             dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
@@ -584,7 +592,7 @@ class _PreluConv2d(Function):
         y2 = torch.empty((N, Ho, Wo, Kp), dtype=y1.dtype, device=y1.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
-                          None, None, None, 1, None, stream())
+                          None, None, None, 1, None, None, stream())
         if pe is not None:
             pe.record()
         ctx.save_for_backward(y1, p1, w, al)
@@ -618,7 +626,7 @@ class _PreluConv2d(Function):
             pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
             lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
-                              0, ptr(y1), ptr(al), ptr(dal_s), sp, None, stream())
+                              0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, stream())
             if sp > 1:
                 lib.xr_reduce_groups(ptr(dal_s), ptr(dal), 1, sp, C, 1 if t_a is not None else 0, stream())
             if t_a is not None:
@@ -636,9 +644,10 @@ def prelu_conv2d(y1, alpha, w, stride=1, pad=0, p1=None):
     return _PreluConv2d.apply(y1, alpha, w, stride, pad, p1)
 
 
-def conv2d_prelu(x, w, alpha, b=None, stride=1, pad=0):
-    """(y, prelu(y, alpha)) with the activation produced by the convolution's epilogue; pass both to prelu_conv2d."""
-    return _Conv2d.apply(x, w, b, stride, pad, alpha)
+def conv2d_prelu(x, w, alpha, b=None, stride=1, pad=0, bn_link=None):
+    """(y, prelu(y, alpha)) with the activation produced by the convolution's epilogue; pass both to prelu_conv2d.
+    bn_link: the BnLink of the BatchNorm whose output `x` is (and which nothing else consumes)."""
+    return _Conv2d.apply(x, w, b, stride, pad, alpha, bn_link)
 
 
 def conv2d(x, w, b=None, stride=1, pad=0):
@@ -662,10 +671,13 @@ class _NormAct(Function):
     ``training``), 'none' (activation / residual add only)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False):
+    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False, link=None):
         x = _c(x)
         N, H, W, C = x.shape
         ctx.passthrough = passthrough
+        ctx.link = link   # see BnLink: the consumer convolution's dgrad may deliver this norm's backward reductions
+        if link is not None:
+            link.x = x    # the exact buffer the statistics were taken over
         if res is not None:
             res = _c(res)
             assert res.shape == x.shape and res.dtype == x.dtype
@@ -729,7 +741,14 @@ class _NormAct(Function):
                 dpass = dpass.to(x.dtype)
         f32 = dict(dtype=torch.float32, device=x.device)
         per_img, N_, HW_ = ctx.per_img
-        if per_img:
+        link_red = ctx.link.take(dy) if ctx.link is not None else None
+        if link_red is not None:
+            # the convolution that consumed this BatchNorm's output already reduced (dy, dy*x) in its dgrad epilogue
+            red, per_img, N_ = link_red, True, link_red.shape[1]
+            if not stats:   # eval-mode norm: the generic path below wants folded sums
+                red = torch.empty((3, 1, C), **f32)
+                lib.xr_reduce_groups(ptr(link_red), ptr(red), 3, N_, C, 0, stream())
+        elif per_img:
             red_n = zeros_f32((3, N_, C), x.device)
             lib.xr_affine_act_bwd_reduce(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(red_n), N_, HW_,
                                          C, 0, stream())
@@ -781,13 +800,38 @@ class _NormAct(Function):
         if dx is not None or dres is not None:
             lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
                                         ptr(dres), G, rows, C, 1, ptr(dpass), stream())
-        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None
 
 
-def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", act=None, training=True, momentum=0.1, eps=EPS):
+class BnLink:
+    """Couples a training-mode BatchNorm (no activation, no residual) with the ONE convolution that consumes its output: the
+    convolution's input-gradient kernel then also accumulates sum(d) and sum(d * x) per channel in its epilogue (ep_red), and
+    the BatchNorm's backward skips its own reduction pass over (d, x).  The norm's backward only trusts a delivery made for
+    exactly the gradient tensor it receives."""
+
+    SPREAD = 32
+
+    def __init__(self):
+        self.x = None         # the BatchNorm's input buffer (same layout as its output), set by the norm's forward
+        self.red = None
+        self.key = None
+
+    def deliver(self, dgrad_out, red):
+        self.red, self.key = red, (dgrad_out.data_ptr(), dgrad_out._version)
+
+    def take(self, dy):
+        red, key = self.red, self.key
+        self.red = self.key = None
+        if red is None or dy is None or key != (dy.data_ptr(), dy._version):
+            return None
+        return red
+
+
+def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", act=None, training=True, momentum=0.1, eps=EPS,
+                  link=None):
     """(norm(x), x'): x' aliases x; route identity branches (block shortcuts) through x' and the two gradients of x are
     summed inside the norm's backward apply kernel instead of by a separate elementwise pass."""
-    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, True)
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, True, link)
 
 
 def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,

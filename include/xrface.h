@@ -81,14 +81,18 @@ int xr_pack_run(const void* table_dev, int n, int blocks, int smem, void* stream
 int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                   int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                   int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
-                  const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, void* stream);
+                  const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, void* stream);
 /* ep_src != NULL fuses a PReLU backward into the epilogue (input gradient of conv(prelu(y)), model_irse.py:59):
  * out = acc * (y > 0 ? 1 : alpha[c]) and dalpha[c] += sum acc*y*[y <= 0], with y = ep_src laid out like `out`.
  * ep_dalpha is [ep_spread][K] fp32, zero-initialised (or holding a running sum) by the caller: row tile i adds its partial
  * sums into row i % ep_spread, so the atomics of thousands of tiles do not all land on the same few cache lines; the
  * caller folds the rows with xr_reduce_groups.  ep_spread <= 1: a single [K] row.
  * ep2_out != NULL (exclusive with ep_src) fuses a PReLU FORWARD: besides `out` the kernel writes ep2_out = prelu(out, ep_alpha)
- * with the same layout -- conv -> PReLU -> conv (model_irse.py:56-60) then needs no separate activation pass. */
+ * with the same layout -- conv -> PReLU -> conv (model_irse.py:56-60) then needs no separate activation pass.
+ * ep_red != NULL (with ep_src = x, the INPUT of the BatchNorm whose output this convolution consumed; the tensor being
+ * written is then dL/d(bn output)): the epilogue also accumulates the two reductions of the BatchNorm backward,
+ * ep_red[0][r][c] += sum d and ep_red[1][r][c] += sum d*x (r = row tile %% ep_spread; layout [3][ep_spread][K], zeroed by the
+ * caller, folded by xr_norm_bwd_coeffs(fold = ep_spread)) -- the separate reduction pass over (d, x) disappears. */
 /* split-K (long reductions with few output tiles, e.g. Linear(25088->512) at batch 256): splitk > 1 slices of the
  * K loop accumulate with fp32 atomics into splitk_ws [N*Ho*Wo][ldo] (zeroed by the caller); `out` is then
  * produced by xr_bias_cast.  splitk_ws == NULL / splitk <= 1: direct epilogue.

@@ -154,11 +154,11 @@ def test_conv2d_8wave_race_screen(shape):
 
     def fwd(out):
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(out), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None,
-                          None, 1, None, stream())
+                          None, 1, None, None, stream())
 
     def dgrad(out):
         lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(out), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None,
-                          None, 1, None, stream())
+                          None, 1, None, None, stream())
 
     try:
         lib.xr_tune(7, 0)
@@ -525,3 +525,44 @@ def test_mmd_against_fp64_restatement():
     (val * 2.0).backward()
     assert abs(val.item() - ref.item()) < 1e-4 * abs(ref.item()) + 1e-7
     assert rel(ag.grad, a64.grad * 2.0) < 1e-3 and rel(bg.grad, b64.grad * 2.0) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,depth,stride,hw", [(64, 64, 1, 20), (64, 128, 2, 28), (256, 256, 1, 14)])
+def test_bn_backward_reduction_fused_into_conv_dgrad(cin, depth, stride, hw, dtype):
+    """bottleneck_IR_SE with the first BatchNorm's backward reductions taken in the first convolution's dgrad epilogue
+    (ops.BnLink) vs the separate reduction pass: same input gradient and parameter gradients; the link must really fire."""
+    import copy
+    import xrface
+    from xrface import ops
+    from xrface.model.model_irse import bottleneck_IR_SE
+    xrface.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(5)
+        blk0 = bottleneck_IR_SE(cin, depth, stride).to(DEV).train()
+        x0 = rnd(f"bl{cin}{depth}", 8 if hw > 14 else 64, cin, hw, hw)
+        res = {}
+        taken = []
+        orig_take = ops.BnLink.take
+
+        def spy(self, dy):
+            r = orig_take(self, dy)
+            taken.append(r is not None)
+            return r
+        ops.BnLink.take = spy
+        for mode in (0, 1):
+            ops._cfg["fuse_bn_reduce"] = mode
+            blk = copy.deepcopy(blk0)
+            x = x0.to(DEV).requires_grad_(True)
+            out = blk(x)
+            out.square().mean().backward()
+            torch.cuda.synchronize()
+            res[mode] = [x.grad.cpu()] + [p.grad.cpu() for p in blk.parameters()]
+        assert taken == [False, True], taken
+        tol = 2e-4 if dtype == torch.float32 else 3e-2
+        for a, b in zip(res[1], res[0]):
+            assert rel(a, b) < tol
+    finally:
+        ops.BnLink.take = orig_take
+        ops._cfg["fuse_bn_reduce"] = 1
+        xrface.set_compute_dtype(torch.float32)
