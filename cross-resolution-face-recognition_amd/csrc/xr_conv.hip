@@ -511,7 +511,12 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
     if (bnr) {  // sums of d and d * x per channel (d as rounded for the output tensor)
       float d[8], xv[8];
       ld8(sp, d);
-      ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+      if (ep_src != nullptr) {
+        ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+      } else {   // statistics of the output itself (sum, sum of squares) for a BatchNorm that follows
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = d[e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         bs0[e] += d[e];
@@ -1509,8 +1514,8 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
   XR_CHECK_ARG(ep_src == nullptr || ep_red != nullptr ||
                    (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
                "xr_conv_igemm: fused PReLU-backward epilogue needs alpha, dalpha, K %% 8 == 0, no bias, no split-K");
-  XR_CHECK_ARG(ep_red == nullptr || (ep_src && K % 8 == 0 && splitk_ws == nullptr && ep2_out == nullptr && out),
-               "xr_conv_igemm: fused BatchNorm-backward reduction needs the BatchNorm input (ep_src), K %% 8 == 0, no split-K");
+  XR_CHECK_ARG(ep_red == nullptr || (K % 8 == 0 && splitk_ws == nullptr && ep2_out == nullptr && out),
+               "xr_conv_igemm: fused per-channel reductions (ep_red) need K %% 8 == 0, no split-K, no second output");
   XR_CHECK_ARG(ep2_out == nullptr || (ep_alpha && ep_src == nullptr && K % 8 == 0 && splitk_ws == nullptr && out),
                "xr_conv_igemm: fused PReLU-forward output needs alpha, K %% 8 == 0, no PReLU-backward epilogue, no split-K");
   XR_CHECK_ARG((splitk_ws == nullptr) == (splitk <= 1), "xr_conv_igemm: split-K needs both a workspace and splitk > 1");

@@ -427,7 +427,12 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
       if (bnr) {  // sums of d and d * x per channel (d as rounded for the output tensor)
         float d[8], xv[8];
         ld8(sp, d);
-        ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+        if (ep_src != nullptr) {
+          ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+        } else {   // statistics of the output itself (sum, sum of squares) for a BatchNorm that follows
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xv[e] = d[e];
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           bs0[e] += d[e];

@@ -72,7 +72,7 @@ class bottleneck_IR(Module):
 
     def _shortcut(self, x):
         if isinstance(self.shortcut_layer, Sequential):
-            return self.shortcut_layer[1].f(self.shortcut_layer[0].f(x))
+            return xnn.conv_bn(self.shortcut_layer[0], self.shortcut_layer[1], x)   # BN statistics out of the conv epilogue
         return self.shortcut_layer.f(x)
 
     def f(self, x):
@@ -152,7 +152,7 @@ class Backbone(Module):
     # -- fused NHWC path ---------------------------------------------------------------------------
     def f_input(self, buf):
         il = self.input_layer
-        return il[1].f(il[0].f(buf), act="prelu", alpha=il[2].weight)
+        return xnn.conv_bn(il[0], il[1], buf, act="prelu", alpha=il[2].weight)
 
     def f_output(self, buf):
         ol = self.output_layer

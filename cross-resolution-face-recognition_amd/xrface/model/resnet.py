@@ -37,9 +37,9 @@ class BasicBlock(Module):
         self.stride = stride
 
     def f(self, x):
-        o = self.bn1.f(self.conv1.f(x), act="relu")
-        res = x if self.downsample is None else self.downsample[1].f(self.downsample[0].f(x))
-        return self.bn2.f(self.conv2.f(o), res=res, act="relu")
+        o = xnn.conv_bn(self.conv1, self.bn1, x, act="relu")            # BN statistics out of the conv epilogues
+        res = x if self.downsample is None else xnn.conv_bn(self.downsample[0], self.downsample[1], x)
+        return xnn.conv_bn(self.conv2, self.bn2, o, res=res, act="relu")
 
     def forward(self, x):
         return leave(self.f(enter(x)))
@@ -91,7 +91,7 @@ class ResNet(Module):
             return self._f(buf)
 
     def _f(self, buf):
-        y = self.bn1.f(self.conv1.f(buf), act="relu")
+        y = xnn.conv_bn(self.conv1, self.bn1, buf, act="relu")
         feats = []
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
             y = xnn.run_seq(layer, y)

@@ -17,10 +17,11 @@ from .ops import enter, leave, leave2d
 
 
 class Conv2d(nn.Conv2d):
-    def f(self, buf):
+    def f(self, buf, stats_link=None):
+        """stats_link: an ops.StatsLink shared with the training-mode BatchNorm that directly consumes the output."""
         assert self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.groups == 1 \
             and self.dilation == (1, 1), "xrface.Conv2d: square stride/padding, no groups/dilation"
-        return ops.conv2d(buf, self.weight, self.bias, self.stride[0], self.padding[0])
+        return ops.conv2d(buf, self.weight, self.bias, self.stride[0], self.padding[0], stats_link)
 
     def forward(self, x):
         return leave(self.f(enter(x)), self.out_channels)
@@ -91,12 +92,13 @@ class _BNMixin:
         if self.training and self.track_running_stats and self.num_batches_tracked is not None and not _NBT_BATCHED[0]:
             self.num_batches_tracked.add_(1)
 
-    def f(self, buf, res=None, act=None, alpha=None):
+    def f(self, buf, res=None, act=None, alpha=None, slink=None):
         training = self.training or not self.track_running_stats
         self._count()
         mom = 0.1 if self.momentum is None else self.momentum
         return ops.norm_act(buf, self.weight, self.bias, self.running_mean, self.running_var, res, alpha, "bn", act, training,
-                            mom, self.eps)
+                            mom, self.eps, slink if training else None)
+
 
 
     def f_pass(self, buf, link=None):
@@ -203,3 +205,9 @@ def run_seq(seq, buf):
     for m in seq:
         buf = m.f(buf)
     return buf
+
+
+def conv_bn(conv, bn, buf, res=None, act=None, alpha=None):
+    """conv -> BatchNorm(+residual, +activation) with the batch statistics taken in the convolution's epilogue."""
+    link = ops.StatsLink() if (bn.training or not bn.track_running_stats) else None
+    return bn.f(conv.f(buf, link), res=res, act=act, alpha=alpha, slink=link)

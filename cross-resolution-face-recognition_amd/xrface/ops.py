@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1}
 
 
 def set_compute_dtype(dtype):
@@ -396,7 +396,7 @@ class _Conv2d(Function):
     """aten::conv2d replacement (weight [K][C][R][S] fp32 Parameter; x NHWC buffer)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None, bn_link=None):
+    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None, bn_link=None, stats_link=None):
         _need_cuda(x)
         ctx.set_materialize_grads(False)   # the non-differentiable PReLU output must not cost a zero-filled gradient tensor
         x = _c(x)
@@ -414,9 +414,16 @@ class _Conv2d(Function):
         if prelu_alpha is not None and K % 8 == 0 and _cfg["fuse_prelu"]:
             al = _c(prelu_alpha.detach().float())
             p2 = torch.empty_like(y)
+        # stats_link: the BatchNorm that follows wants sum / sum of squares of y per channel: taken in the epilogue
+        sred, ssp = None, 1
+        if stats_link is not None and p2 is None and K % 8 == 0 and _cfg["fuse_conv_stats"]:
+            ssp = StatsLink.SPREAD
+            sred = zeros_f32((3, ssp, Kp), x.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, None, ptr(al), None, 1, ptr(p2), None, stream())
+                          kg, Kp, None, 0, None, ptr(al), None, ssp, ptr(p2), ptr(sred), stream())
+        if sred is not None:
+            stats_link.deliver(y, sred)
         if pe is not None:
             pe.record()
         ctx.save_for_backward(x, w)
@@ -435,7 +442,7 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy, _dp2=None):
         if dy is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, w = ctx.saved_tensors
         stride, pad, has_b = ctx.geom
         dy = _c(dy)
@@ -463,7 +470,7 @@ class _Conv2d(Function):
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 class _ConvTranspose2d(Function):
@@ -650,8 +657,29 @@ def conv2d_prelu(x, w, alpha, b=None, stride=1, pad=0, bn_link=None):
     return _Conv2d.apply(x, w, b, stride, pad, alpha, bn_link)
 
 
-def conv2d(x, w, b=None, stride=1, pad=0):
-    return _Conv2d.apply(x, w, b, stride, pad)
+class StatsLink:
+    """Couples a convolution with the training-mode BatchNorm that directly follows it: the convolution's epilogue takes the
+    per-channel sum / sum of squares of its output (ep_red with ep_src = NULL) and the norm skips its statistics pass."""
+
+    SPREAD = 32
+
+    def __init__(self):
+        self.sums = None
+        self.key = None
+
+    def deliver(self, y, sums):
+        self.sums, self.key = sums, (y.data_ptr(), y._version, tuple(y.shape))
+
+    def take(self, x):
+        sums, key = self.sums, self.key
+        self.sums = self.key = None
+        if sums is None or key != (x.data_ptr(), x._version, tuple(x.shape)):
+            return None
+        return sums
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, stats_link=None):
+    return _Conv2d.apply(x, w, b, stride, pad, None, None, stats_link)
 
 
 def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0):
@@ -671,7 +699,8 @@ class _NormAct(Function):
     ``training``), 'none' (activation / residual add only)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False, link=None):
+    def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False, link=None,
+                slink=None):
         x = _c(x)
         N, H, W, C = x.shape
         ctx.passthrough = passthrough
@@ -695,7 +724,15 @@ class _NormAct(Function):
         if per_img:  # pseudo-groups: the largest divisor of N that is <= 32
             pg = max(d for d in range(1, min(N, 32) + 1) if N % d == 0)
             per_img = pg > 1
-        if stats:
+        pre = slink.take(x) if (slink is not None and stats and mode == "bn") else None
+        if pre is not None:   # the producing convolution already summed x and x^2 per channel (StatsLink)
+            mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
+            scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
+            upd = rmean is not None
+            lib.xr_norm_finalize(ptr(pre), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                 ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
+                                 pre.shape[1], stream())
+        elif stats:
             if per_img:
                 sums_n = zeros_f32((2, pg, C), dev)
                 lib.xr_group_stats(dt(x), ptr(x), ptr(sums_n), pg, (N // pg) * H * W, C, stream())
@@ -800,7 +837,7 @@ class _NormAct(Function):
         if dx is not None or dres is not None:
             lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
                                         ptr(dres), G, rows, C, 1, ptr(dpass), stream())
-        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None
 
 
 class BnLink:
@@ -835,8 +872,8 @@ def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", ac
 
 
 def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,
-             momentum=0.1, eps=EPS):
-    return _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps)
+             momentum=0.1, eps=EPS, slink=None):
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, False, None, slink)
 
 
 # ------------------------------------------------------------------------------------------------- SE

@@ -92,7 +92,9 @@ int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, v
  * ep_red != NULL (with ep_src = x, the INPUT of the BatchNorm whose output this convolution consumed; the tensor being
  * written is then dL/d(bn output)): the epilogue also accumulates the two reductions of the BatchNorm backward,
  * ep_red[0][r][c] += sum d and ep_red[1][r][c] += sum d*x (r = row tile %% ep_spread; layout [3][ep_spread][K], zeroed by the
- * caller, folded by xr_norm_bwd_coeffs(fold = ep_spread)) -- the separate reduction pass over (d, x) disappears. */
+ * caller, folded by xr_norm_bwd_coeffs(fold = ep_spread)) -- the separate reduction pass over (d, x) disappears.
+ * ep_red != NULL with ep_src == NULL: x := the output itself, i.e. ep_red[0] / ep_red[1] receive the per-channel sum and sum
+ * of squares of `out` -- the batch statistics of a BatchNorm that follows the convolution (xr_norm_finalize(fold = ep_spread)). */
 /* split-K (long reductions with few output tiles, e.g. Linear(25088->512) at batch 256): splitk > 1 slices of the
  * K loop accumulate with fp32 atomics into splitk_ws [N*Ho*Wo][ldo] (zeroed by the caller); `out` is then
  * produced by xr_bias_cast.  splitk_ws == NULL / splitk <= 1: direct epilogue.
