@@ -177,6 +177,12 @@ def main():
         opt.step()
         return loss
 
+    # the step runs on a high-priority stream: the side stream that carries the weight gradients (normal priority) then
+    # yields to the forward / dgrad / norm-backward chain instead of competing with it (-0.1 ms/step in-process)
+    hp = torch.cuda.Stream(dev, priority=-1)
+    hp.wait_stream(torch.cuda.current_stream(dev))
+    hp_ctx = torch.cuda.stream(hp)
+    hp_ctx.__enter__()
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -203,6 +209,8 @@ def main():
         el = float(t.item())
     final_loss = float(loss.item())
     assert final_loss == final_loss, "loss is NaN"
+    hp_ctx.__exit__(None, None, None)
+    torch.cuda.current_stream(dev).wait_stream(hp)
 
     if rank == 0:
         ms = el / args.steps * 1e3
