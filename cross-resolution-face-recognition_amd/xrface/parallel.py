@@ -54,7 +54,7 @@ class BucketedAllReduce:
     model that applies one parameter at several sites (the shared FSRNet trunks), because the direct-accumulation
     path signals per site, not per parameter."""
 
-    def __init__(self, flat: FlatParams, bucket_mb: float = 48.0, group=None, overlap: bool = True):
+    def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
