@@ -162,6 +162,7 @@ class FusedSGD(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        ops.join_side_stream()   # no-op unless a backward pass ended without its end-of-backward join (e.g. it raised)
         g = self.param_groups[0]
         lib.xr_sgd_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.mom), self.flat.numel, g["lr"], g["momentum"],
                         g["weight_decay"], ptr(self.mask), int(self._steps == 0), stream())
@@ -178,6 +179,7 @@ class FusedRMSprop(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        ops.join_side_stream()   # no-op unless a backward pass ended without its end-of-backward join (e.g. it raised)
         g = self.param_groups[0]
         lib.xr_rmsprop_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.sq), self.flat.numel, g["lr"], g["alpha"],
                             g["eps"], g["weight_decay"], stream())
@@ -195,6 +197,7 @@ class FusedAdam(_FlatOptimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        ops.join_side_stream()   # no-op unless a backward pass ended without its end-of-backward join (e.g. it raised)
         g = self.param_groups[0]
         self._steps += 1
         cap = ops._graph["capturing"]
