@@ -40,6 +40,7 @@ class FlatParams:
     def zero_grad(self):
         """One memset; .grad tensors stay allocated views (autograd accumulates in place)."""
         ops.join_side_stream()
+        ops._side["cb"] = False   # a backward pass that raised never ran its end-of-backward callback: re-arm it
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
