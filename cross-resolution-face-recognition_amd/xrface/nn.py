@@ -59,6 +59,14 @@ class InstanceNorm2d(nn.InstanceNorm2d):
         return leave(self.f(enter(x)))
 
 
+def buf_is_cuda(t):
+    return t is not None and t.is_cuda
+
+
+def _any_requires_grad(bn):
+    return (bn.weight is not None and bn.weight.requires_grad) or (bn.bias is not None and bn.bias.requires_grad)
+
+
 _NBT_BATCHED = [False]  # set by batched_bn_counters(): the per-layer counter increments were issued as one foreach op
 
 
@@ -92,12 +100,27 @@ class _BNMixin:
         if self.training and self.track_running_stats and self.num_batches_tracked is not None and not _NBT_BATCHED[0]:
             self.num_batches_tracked.add_(1)
 
+    def _eval_coef(self):
+        """Eval mode: scale / shift depend only on the parameters and running statistics -- computed once per version of
+        those four tensors (a frozen teacher or an inference backbone then launches nothing per forward for them)."""
+        if not buf_is_cuda(self.running_mean):
+            return None
+        tensors = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors) + (ops._pack_epoch[0],
+              self.weight.__dict__.get("_xr_epoch", 0) if self.weight is not None else 0)
+        hit = self.__dict__.get("_xr_eval_coef")
+        if hit is None or hit[0] != key:
+            hit = (key, ops.bn_eval_coeffs(self.weight, self.bias, self.running_mean, self.running_var, self.eps))
+            self.__dict__["_xr_eval_coef"] = hit
+        return hit[1]
+
     def f(self, buf, res=None, act=None, alpha=None, slink=None):
         training = self.training or not self.track_running_stats
         self._count()
         mom = 0.1 if self.momentum is None else self.momentum
+        coef = None if training or torch.is_grad_enabled() and _any_requires_grad(self) else self._eval_coef()
         return ops.norm_act(buf, self.weight, self.bias, self.running_mean, self.running_var, res, alpha, "bn", act, training,
-                            mom, self.eps, slink if training else None)
+                            mom, self.eps, slink if training else None, coef)
 
 
 

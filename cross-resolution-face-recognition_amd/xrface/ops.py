@@ -700,7 +700,7 @@ class _NormAct(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False, link=None,
-                slink=None):
+                slink=None, eval_coef=None):
         x = _c(x)
         N, H, W, C = x.shape
         ctx.passthrough = passthrough
@@ -750,8 +750,11 @@ class _NormAct(Function):
                                  ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
                                  pg if (per_img and _cfg["fold_finalize"]) else 1, stream())
         elif mode == "bn":
-            scale, shift = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
-            lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
+            if eval_coef is not None:   # frozen network: (scale, shift) cached by the layer (nn._BNMixin)
+                scale, shift = eval_coef
+            else:
+                scale, shift = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
+                lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
         y = torch.empty_like(x)
         a = _ACT[act]
         lib.xr_affine_act(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), G, rows, C, 1, stream())
@@ -837,7 +840,7 @@ class _NormAct(Function):
         if dx is not None or dres is not None:
             lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
                                         ptr(dres), G, rows, C, 1, ptr(dpass), stream())
-        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None, None
 
 
 class BnLink:
@@ -872,8 +875,19 @@ def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", ac
 
 
 def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,
-             momentum=0.1, eps=EPS, slink=None):
-    return _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, False, None, slink)
+             momentum=0.1, eps=EPS, slink=None, eval_coef=None):
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, False, None, slink, eval_coef)
+
+
+def bn_eval_coeffs(gamma, beta, rmean, rvar, eps):
+    """(scale, shift) [1][C] fp32 of an eval-mode BatchNorm."""
+    C = rmean.numel()
+    f32 = dict(dtype=torch.float32, device=rmean.device)
+    gm = None if gamma is None else _c(gamma.detach().float())
+    bt = None if beta is None else _c(beta.detach().float())
+    scale, shift = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
+    lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
+    return scale, shift
 
 
 # ------------------------------------------------------------------------------------------------- SE
