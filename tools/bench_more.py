@@ -123,4 +123,13 @@ t0 = time.perf_counter()
 tpr, fpr, acc, best = calculate_roc(np.arange(0, 12000, 3), e1, e2, same.cpu().numpy(), nrof_folds=10, fold_id=fold)
 torch.cuda.synchronize()
 out["C5 calculate_roc P=1e6 (incl. host prefix sums)"] = {"ms": round((time.perf_counter() - t0) * 1e3, 1), "acc": round(float(acc), 4)}
+
+# ---- embedding extraction (the forward half of the evaluation path): IR-SE-50 eval forward, bf16
+xrface.set_compute_dtype(torch.bfloat16)
+n = int(os.environ.get("EMB_N", 256))
+net = model_irse.IR_SE_50([112, 112]).to(dev).eval()
+xe = faces(n)
+with torch.no_grad():
+    ms = timed(lambda: net(xe), warm=3, reps=8)
+out[f"IR-SE-50 eval forward N={n} bf16"] = {"ms": round(ms, 3), "img_s": round(n / ms * 1e3, 1)}
 print(json.dumps(out, indent=1))
