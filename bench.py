@@ -57,7 +57,7 @@ def dominant_kernel_roofline(dev, dtype, batch, probe_events, reps=10):
     y = torch.empty(N, H, H, K, device=dev, dtype=dtype)
 
     def launch():
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, H, H, K, 3, 3, 1, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, stream())
+        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, H, H, K, 3, 3, 1, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, None, stream())
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -530,6 +530,15 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
       for (int e = 0; e < 8; ++e) o[e] = d[e] > 0.f ? d[e] : d[e] * alv[e];
       st8(out2 + (size_t)m * p.ldo + ncol, o);
     }
+    if (p.ep_add != nullptr) {   // gradient of an identity branch summed here instead of by a separate elementwise pass
+      float d[8], av[8];
+      ld8(sp, d);
+      ld8(reinterpret_cast<const out_t*>(p.ep_add) + (size_t)m * p.ldo + ncol, av);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] += av[e];
+      st8(dp, d);
+      continue;
+    }
     if (ncol + 8 <= Kw) {
       if constexpr (sizeof(out_t) == 2) {
         *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
@@ -1509,7 +1518,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
 extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                              int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
-                             const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, void* stream) {
+                             const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, const void* ep_add, void* stream) {
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
   XR_CHECK_ARG(ep_src == nullptr || ep_red != nullptr ||
                    (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
@@ -1518,6 +1527,8 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                "xr_conv_igemm: fused per-channel reductions (ep_red) need K %% 8 == 0, no split-K, no second output");
   XR_CHECK_ARG(ep2_out == nullptr || (ep_alpha && ep_src == nullptr && K % 8 == 0 && splitk_ws == nullptr && out),
                "xr_conv_igemm: fused PReLU-forward output needs alpha, K %% 8 == 0, no PReLU-backward epilogue, no split-K");
+  XR_CHECK_ARG(ep_add == nullptr || (K % 8 == 0 && ep_src == nullptr && ep2_out == nullptr && ep_red == nullptr && splitk_ws == nullptr && out),
+               "xr_conv_igemm: fused gradient sum (ep_add) needs K %% 8 == 0 and no other epilogue fusion / split-K");
   XR_CHECK_ARG((splitk_ws == nullptr) == (splitk <= 1), "xr_conv_igemm: split-K needs both a workspace and splitk > 1");
   XR_CHECK_ARG(in && w && (out || splitk_ws), "xr_conv_igemm: null pointer");
   XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
@@ -1536,7 +1547,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                  stride, pad);
   }
   IgemmP p{in, (const bf16_t*)w, bias, out, N, H, W, C, Ho, Wo, K, R, S, stride, pad, Kg, ldo,
-           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, ep_spread > 0 ? ep_spread : 1, ep2_out, ep_red, g_tune[4]};
+           N * Ho * Wo, 0, 0, 0, 0, splitk_ws, splitk > 1 ? splitk : 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha, ep_dalpha, ep_spread > 0 ? ep_spread : 1, ep2_out, ep_red, ep_add, g_tune[4]};
   hipStream_t st = (hipStream_t)stream;
   if (xr_igemm8_eligible(p, dtype, transposed)) return xr_igemm8_launch(p, transposed, st);
   const bool wide = K > 64 && g_tune[3] == 0;

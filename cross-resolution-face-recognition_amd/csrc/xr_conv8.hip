@@ -422,6 +422,13 @@ __global__ __launch_bounds__(NT8, 1) void igemm8_kernel(IgemmP p) {
         if (neg) dal[e] += d[e] * yv[e];
       }
       st8(dp, o);
+    } else if (p.ep_add != nullptr) {   // gradient of an identity branch summed here
+      float d[8], av[8];
+      ld8(sp, d);
+      ld8(reinterpret_cast<const bf16_t*>(p.ep_add) + (size_t)m * p.ldo + ncol, av);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] += av[e];
+      st8(dp, d);
     } else {
       *reinterpret_cast<uint4*>(dp) = *reinterpret_cast<const uint4*>(sp);
       if (bnr) {  // sums of d and d * x per channel (d as rounded for the output tensor)

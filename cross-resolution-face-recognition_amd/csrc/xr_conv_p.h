@@ -47,6 +47,8 @@ struct IgemmP {
   // fused BatchNorm-backward reduction (the tensor being written is dL/d(bn output), ep_src = the BatchNorm's INPUT x):
   // ep_red[0][row][c] += sum d, ep_red[1][row][c] += sum d * x with row = row tile % ep_spread; layout [3][ep_spread][K]
   float* ep_red;
+  // fused gradient sum: out += ep_add (same layout as out) -- the gradient arriving through an identity branch of the same input
+  const void* ep_add;
   int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
 };
 

@@ -31,8 +31,11 @@ class _Residual_Block(nn.Module):
         self.relu_out = xnn.PReLU(out_channels)
 
     def f(self, x):
-        y = self.in1.f(self.conv1.f(x), act="prelu", alpha=self.relu.weight)
-        return self.in2.f(self.conv2.f(y), res=x, act="prelu", alpha=self.relu_out.weight)
+        # the block input feeds conv1 and the residual add: route the residual through conv1's pass-through output so the
+        # two gradients of x meet in conv1's dgrad epilogue instead of in a separate elementwise add
+        c1, xs = self.conv1.f_pass(x)
+        y = self.in1.f(c1, act="prelu", alpha=self.relu.weight)
+        return self.in2.f(self.conv2.f(y), res=xs, act="prelu", alpha=self.relu_out.weight)
 
     def forward(self, x):
         return leave(self.f(enter(x)))
@@ -58,8 +61,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def f(self, x):
-        y = self.bn1.f(self.conv1.f(x), act="prelu", alpha=self.relu.weight)
-        res = x if self.downsample is None else self.downsample.f(x)
+        if self.downsample is None:
+            c1, res = self.conv1.f_pass(x)      # residual gradient summed in conv1's dgrad epilogue
+        else:
+            c1, res = self.conv1.f(x), self.downsample.f(x)
+        y = self.bn1.f(c1, act="prelu", alpha=self.relu.weight)
         return self.bn2.f(self.conv2.f(y), res=res, act="prelu", alpha=self.relu.weight)
 
     def forward(self, x):

@@ -23,6 +23,10 @@ class Conv2d(nn.Conv2d):
             and self.dilation == (1, 1), "xrface.Conv2d: square stride/padding, no groups/dilation"
         return ops.conv2d(buf, self.weight, self.bias, self.stride[0], self.padding[0], stats_link)
 
+    def f_pass(self, buf):
+        """(conv(buf), buf'): buf' aliases buf and carries the residual-branch gradient into this conv's dgrad epilogue."""
+        return ops.conv2d_pass(buf, self.weight, self.bias, self.stride[0], self.padding[0])
+
     def forward(self, x):
         return leave(self.f(enter(x)), self.out_channels)
 

@@ -396,7 +396,7 @@ class _Conv2d(Function):
     """aten::conv2d replacement (weight [K][C][R][S] fp32 Parameter; x NHWC buffer)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None, bn_link=None, stats_link=None):
+    def forward(ctx, x, w, b, stride, pad, prelu_alpha=None, bn_link=None, stats_link=None, passthrough=False):
         _need_cuda(x)
         ctx.set_materialize_grads(False)   # the non-differentiable PReLU output must not cost a zero-filled gradient tensor
         x = _c(x)
@@ -421,7 +421,7 @@ class _Conv2d(Function):
             sred = zeros_f32((3, ssp, Kp), x.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, None, ptr(al), None, ssp, ptr(p2), ptr(sred), stream())
+                          kg, Kp, None, 0, None, ptr(al), None, ssp, ptr(p2), ptr(sred), None, stream())
         if sred is not None:
             stats_link.deliver(y, sred)
         if pe is not None:
@@ -430,6 +430,9 @@ class _Conv2d(Function):
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
         ctx.bn_link = bn_link
+        ctx.passthrough = passthrough and prelu_alpha is None
+        if ctx.passthrough:   # second output aliases the input: its gradient is summed into dx by the dgrad epilogue (ep_add)
+            return y, x.view_as(x)
         if prelu_alpha is not None:
             if p2 is None:
                 p2 = torch.empty_like(y)
@@ -442,7 +445,7 @@ class _Conv2d(Function):
     @staticmethod
     def backward(ctx, dy, _dp2=None):
         if dy is None:
-            return None, None, None, None, None, None, None, None
+            return (_dp2 if ctx.passthrough else None), None, None, None, None, None, None, None, None
         x, w = ctx.saved_tensors
         stride, pad, has_b = ctx.geom
         dy = _c(dy)
@@ -460,17 +463,28 @@ class _Conv2d(Function):
                     and link.x.dtype == x.dtype:
                 sp_ = BnLink.SPREAD
                 red = zeros_f32((3, sp_, C), x.device)
+            dpass = _dp2 if ctx.passthrough else None
+            if dpass is not None:
+                dpass = _c(dpass)
+                if dpass.dtype != x.dtype:
+                    dpass = dpass.to(x.dtype)
+            add_in_kernel = dpass is not None and red is None and C % 8 == 0
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red), stream())
+                              kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red),
+                              ptr(dpass) if add_in_kernel else None, stream())
+            if dpass is not None and not add_in_kernel:
+                dx = dx + dpass
             if red is not None:
                 link.deliver(dx, red)
+        if dx is None and ctx.passthrough and _dp2 is not None:
+            dx = _dp2
         if ctx.needs_input_grad[1]:
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         if has_b and ctx.needs_input_grad[2]:
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 class _ConvTranspose2d(Function):
@@ -490,7 +504,7 @@ class _ConvTranspose2d(Function):
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
-                          kg, Kp, None, 0, None, None, None, 1, None, None, stream())
+                          kg, Kp, None, 0, None, None, None, 1, None, None, None, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
         ctx.bias_ref = b
@@ -512,7 +526,7 @@ class _ConvTranspose2d(Function):
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
-                              kg, Cp, None, 0, None, None, None, 1, None, None, stream())
+                              kg, Cp, None, 0, None, None, None, 1, None, None, None, stream())
         if ctx.needs_input_grad[1]:
             # dw[ci][co][r][s] = sum_{n,hi,wi} x[n,hi,wi,ci] * dy[n, hi*s - p + r, wi*s - p + s', co]: the weight gradient of an
             # ordinary strided convolution whose input is dy and whose output gradient is x -- rows = ci, cols = (tap, co),
@@ -544,11 +558,11 @@ class _LinearNHWC(Function):
         split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None, None,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None, None, None,
                               stream())
             lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None, None,
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None, None, None,
                               stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -570,7 +584,7 @@ class _LinearNHWC(Function):
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
-                              HW * C, None, 0, None, None, None, 1, None, None, stream())
+                              HW * C, None, 0, None, None, None, 1, None, None, None, stream())
         if ctx.needs_input_grad[1]:
             kg = kg_of(HW, C)
             dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
@@ -599,7 +613,7 @@ class _PreluConv2d(Function):
         y2 = torch.empty((N, Ho, Wo, Kp), dtype=y1.dtype, device=y1.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
-                          None, None, None, 1, None, None, stream())
+                          None, None, None, 1, None, None, None, stream())
         if pe is not None:
             pe.record()
         ctx.save_for_backward(y1, p1, w, al)
@@ -633,7 +647,7 @@ class _PreluConv2d(Function):
             pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
             lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
-                              0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, stream())
+                              0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, None, stream())
             if sp > 1:
                 lib.xr_reduce_groups(ptr(dal_s), ptr(dal), 1, sp, C, 1 if t_a is not None else 0, stream())
             if t_a is not None:
@@ -680,6 +694,12 @@ class StatsLink:
 
 def conv2d(x, w, b=None, stride=1, pad=0, stats_link=None):
     return _Conv2d.apply(x, w, b, stride, pad, None, None, stats_link)
+
+
+def conv2d_pass(x, w, b=None, stride=1, pad=0):
+    """(conv(x), x'): x' aliases x; route the identity / residual branch through x' and its gradient is added to the
+    convolution's input gradient inside the dgrad epilogue instead of by a separate elementwise pass."""
+    return _Conv2d.apply(x, w, b, stride, pad, None, None, None, True)
 
 
 def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0):

@@ -81,7 +81,7 @@ int xr_pack_run(const void* table_dev, int n, int blocks, int smem, void* stream
 int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, void* out,
                   int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                   int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
-                  const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, void* stream);
+                  const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, const void* ep_add, void* stream);
 /* ep_src != NULL fuses a PReLU backward into the epilogue (input gradient of conv(prelu(y)), model_irse.py:59):
  * out = acc * (y > 0 ? 1 : alpha[c]) and dalpha[c] += sum acc*y*[y <= 0], with y = ep_src laid out like `out`.
  * ep_dalpha is [ep_spread][K] fp32, zero-initialised (or holding a running sum) by the caller: row tile i adds its partial
@@ -94,7 +94,9 @@ int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, v
  * ep_red[0][r][c] += sum d and ep_red[1][r][c] += sum d*x (r = row tile %% ep_spread; layout [3][ep_spread][K], zeroed by the
  * caller, folded by xr_norm_bwd_coeffs(fold = ep_spread)) -- the separate reduction pass over (d, x) disappears.
  * ep_red != NULL with ep_src == NULL: x := the output itself, i.e. ep_red[0] / ep_red[1] receive the per-channel sum and sum
- * of squares of `out` -- the batch statistics of a BatchNorm that follows the convolution (xr_norm_finalize(fold = ep_spread)). */
+ * of squares of `out` -- the batch statistics of a BatchNorm that follows the convolution (xr_norm_finalize(fold = ep_spread)).
+ * ep_add != NULL (no other epilogue fusion): out += ep_add (same layout) -- the input gradient arriving through an identity /
+ * residual branch of the same input is summed in the dgrad epilogue instead of by a separate elementwise pass. */
 /* split-K (long reductions with few output tiles, e.g. Linear(25088->512) at batch 256): splitk > 1 slices of the
  * K loop accumulate with fp32 atomics into splitk_ws [N*Ho*Wo][ldo] (zeroed by the caller); `out` is then
  * produced by xr_bias_cast.  splitk_ws == NULL / splitk <= 1: direct epilogue.

@@ -26,9 +26,9 @@ def test_argument_validation_without_gpu():
     """Entry points validate arguments before touching the device."""
     from xrface import _lib
     with pytest.raises(RuntimeError, match="xr_conv_igemm"):
-        _lib.lib.xr_conv_igemm(0, None, None, None, None, 1, 1, 1, 8, 1, 1, 8, 1, 1, 1, 0, 0, 64, 8, None, 0, None, None, None, 1, None, None, None)
+        _lib.lib.xr_conv_igemm(0, None, None, None, None, 1, 1, 1, 8, 1, 1, 8, 1, 1, 1, 0, 0, 64, 8, None, 0, None, None, None, 1, None, None, None, None)
     with pytest.raises(RuntimeError, match="multiple of 8"):
-        _lib.lib.xr_conv_igemm(0, 16, 16, None, 16, 1, 4, 4, 3, 4, 4, 8, 3, 3, 1, 1, 0, 64, 8, None, 0, None, None, None, 1, None, None, None)
+        _lib.lib.xr_conv_igemm(0, 16, 16, None, 16, 1, 4, 4, 3, 4, 4, 8, 3, 3, 1, 1, 0, 64, 8, None, 0, None, None, None, 1, None, None, None, None)
 
 
 @pytest.mark.parametrize("name,ctor", [

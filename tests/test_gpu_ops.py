@@ -154,11 +154,11 @@ def test_conv2d_8wave_race_screen(shape):
 
     def fwd(out):
         lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(out), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None,
-                          None, 1, None, None, stream())
+                          None, 1, None, None, None, stream())
 
     def dgrad(out):
         lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(out), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None,
-                          None, 1, None, None, stream())
+                          None, 1, None, None, None, stream())
 
     try:
         lib.xr_tune(7, 0)

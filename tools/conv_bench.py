@@ -52,11 +52,11 @@ def main():
         ref = None
         for v in variants:
             lib.xr_tune(0, v[0]); lib.xr_tune(2, 1 - v[1]); lib.xr_tune(3, v[2]); lib.xr_tune(4, v[3]); lib.xr_tune(7, v[4])
-            f = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, stream()))
-            d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None, None, 1, None, None, stream()))
+            f = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, None, stream()))
+            d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None, None, 1, None, None, None, stream()))
             if os.environ.get("EP"):  # dgrad with the fused PReLU-backward epilogue instead of the plain one
                 sp = int(os.environ.get('EP')); al = torch.full((C,), 0.25, device=dev); dal = torch.zeros(sp, C, device=dev)
-                d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, ptr(x), ptr(al), ptr(dal), sp, None, None, stream()))
+                d = timeit(lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, ptr(x), ptr(al), ptr(dal), sp, None, None, None, stream()))
             g = timeit(lambda: lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slab), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, K, kg, split, stream()))
             torch.cuda.synchronize()
             cur = (y.float().clone(), dx.float().clone())

@@ -19,7 +19,7 @@ pkd, kgd = ops._packed(w, "dgrad", dtype, C, 1, 9, K, K, 9, 0, 1, C * 9)
 split = ops._wgrad_split(N * Ho * Ho, K, kg)
 slab = torch.zeros(split, K, kg, device=dev)
 for _ in range(int(os.environ.get("REPS", 3))):
-    lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, stream())
-    lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None, None, 1, None, None, stream())
+    lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, None, stream())
+    lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pkd), None, ptr(dx), N, Ho, Ho, K, H, H, C, 3, 3, st, 1, 1, kgd, C, None, 0, None, None, None, 1, None, None, None, stream())
     lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slab), N, H, H, C, Ho, Ho, K, 3, 3, st, 1, 0, K, kg, split, stream())
 torch.cuda.synchronize()
