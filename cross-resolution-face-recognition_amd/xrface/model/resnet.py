@@ -37,8 +37,13 @@ class BasicBlock(Module):
         self.stride = stride
 
     def f(self, x):
-        o = xnn.conv_bn(self.conv1, self.bn1, x, act="relu")            # BN statistics out of the conv epilogues
-        res = x if self.downsample is None else xnn.conv_bn(self.downsample[0], self.downsample[1], x)
+        # BN statistics out of the conv epilogues; an identity residual goes through conv1's pass-through output so that its
+        # gradient is summed in conv1's dgrad epilogue
+        if self.downsample is None:
+            o, res = xnn.conv_bn(self.conv1, self.bn1, x, act="relu", pass_through=True)
+        else:
+            o = xnn.conv_bn(self.conv1, self.bn1, x, act="relu")
+            res = xnn.conv_bn(self.downsample[0], self.downsample[1], x)
         return xnn.conv_bn(self.conv2, self.bn2, o, res=res, act="relu")
 
     def forward(self, x):

@@ -23,9 +23,9 @@ class Conv2d(nn.Conv2d):
             and self.dilation == (1, 1), "xrface.Conv2d: square stride/padding, no groups/dilation"
         return ops.conv2d(buf, self.weight, self.bias, self.stride[0], self.padding[0], stats_link)
 
-    def f_pass(self, buf):
+    def f_pass(self, buf, stats_link=None):
         """(conv(buf), buf'): buf' aliases buf and carries the residual-branch gradient into this conv's dgrad epilogue."""
-        return ops.conv2d_pass(buf, self.weight, self.bias, self.stride[0], self.padding[0])
+        return ops.conv2d_pass(buf, self.weight, self.bias, self.stride[0], self.padding[0], stats_link)
 
     def forward(self, x):
         return leave(self.f(enter(x)), self.out_channels)
@@ -234,7 +234,11 @@ def run_seq(seq, buf):
     return buf
 
 
-def conv_bn(conv, bn, buf, res=None, act=None, alpha=None):
-    """conv -> BatchNorm(+residual, +activation) with the batch statistics taken in the convolution's epilogue."""
+def conv_bn(conv, bn, buf, res=None, act=None, alpha=None, pass_through=False):
+    """conv -> BatchNorm(+residual, +activation) with the batch statistics taken in the convolution's epilogue.
+    pass_through: also return buf' (aliasing buf) for an identity branch whose gradient the conv's dgrad epilogue sums in."""
     link = ops.StatsLink() if (bn.training or not bn.track_running_stats) else None
+    if pass_through:
+        y, bufp = conv.f_pass(buf, link)
+        return bn.f(y, res=res, act=act, alpha=alpha, slink=link), bufp
     return bn.f(conv.f(buf, link), res=res, act=act, alpha=alpha, slink=link)

@@ -696,10 +696,10 @@ def conv2d(x, w, b=None, stride=1, pad=0, stats_link=None):
     return _Conv2d.apply(x, w, b, stride, pad, None, None, stats_link)
 
 
-def conv2d_pass(x, w, b=None, stride=1, pad=0):
+def conv2d_pass(x, w, b=None, stride=1, pad=0, stats_link=None):
     """(conv(x), x'): x' aliases x; route the identity / residual branch through x' and its gradient is added to the
     convolution's input gradient inside the dgrad epilogue instead of by a separate elementwise pass."""
-    return _Conv2d.apply(x, w, b, stride, pad, None, None, None, True)
+    return _Conv2d.apply(x, w, b, stride, pad, None, None, stats_link, True)
 
 
 def conv_transpose2d(x, w, b=None, stride=1, pad=0, out_pad=0):
