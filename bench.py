@@ -160,7 +160,7 @@ def main():
     model = IR_SE_50([112, 112]).to(dev)
     model.train()
     parallel.broadcast_module(model)
-    flat = parallel.FlatParams(model.parameters())
+    flat = parallel.FlatParams(model.parameters_in_execution_order())
     bn_params = [p for n_, p in model.named_parameters() if p.dim() == 1]
     opt = parallel.FusedSGD(flat, lr=0.05, momentum=0.9, weight_decay=5e-4, no_decay=bn_params)
     reducer = parallel.BucketedAllReduce(flat)

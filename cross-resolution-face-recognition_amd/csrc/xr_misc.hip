@@ -507,8 +507,10 @@ __global__ __launch_bounds__(NT) void mmd_bwd_kernel(const float* __restrict__ z
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom, int64_t n, float lr,
                            float momentum, float wd, const uint8_t* __restrict__ wd_mask, int first) {
   GRID_STRIDE(i, n) {
+    const int mk = wd_mask ? wd_mask[i] : 1;
+    if (mk & 2) continue;   // parameter received no gradient this step: skipped, like a stock optimizer skips .grad None
     float gi = g[i];
-    if (wd != 0.f && (wd_mask == nullptr || wd_mask[i])) gi += wd * p[i];
+    if (wd != 0.f && (mk & 1)) gi += wd * p[i];
     if (momentum != 0.f) {
       const float b = first ? gi : momentum * mom[i] + gi;
       mom[i] = b;
@@ -518,10 +520,12 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
   }
 }
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, int64_t n, float lr,
-                               float alpha, float eps, float wd) {
+                               float alpha, float eps, float wd, const uint8_t* __restrict__ wd_mask) {
   GRID_STRIDE(i, n) {
+    const int mk = wd_mask ? wd_mask[i] : 1;
+    if (mk & 2) continue;
     float gi = g[i];
-    if (wd != 0.f) gi += wd * p[i];
+    if (wd != 0.f && (mk & 1)) gi += wd * p[i];
     const float v = alpha * sq[i] + (1.f - alpha) * gi * gi;
     sq[i] = v;
     p[i] -= lr * gi / (sqrtf(v) + eps);
@@ -529,15 +533,17 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
 }
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2, int step,
-                            const uint64_t* __restrict__ tick, uint64_t tick_ref) {
+                            const uint64_t* __restrict__ tick, uint64_t tick_ref, const uint8_t* __restrict__ wd_mask) {
   if (tick != nullptr) {  // replayed HIP graph: the bias corrections follow the device-side step counter
     const float st = (float)(step + (int)(*tick - tick_ref));
     bc1 = 1.f - powf(b1, st);
     bc2 = 1.f - powf(b2, st);
   }
   GRID_STRIDE(i, n) {
+    const int mk = wd_mask ? wd_mask[i] : 1;
+    if (mk & 2) continue;
     float gi = g[i];
-    if (wd != 0.f) gi += wd * p[i];
+    if (wd != 0.f && (mk & 1)) gi += wd * p[i];
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -843,18 +849,19 @@ extern "C" int xr_sgd_step(float* p, const float* g, float* mom, int64_t n, floa
   return XR_OK;
 }
 extern "C" int xr_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float wd,
-                               void* stream) {
+                               const uint8_t* wd_mask, void* stream) {
   XR_CHECK_ARG(p && g && sq && n > 0, "xr_rmsprop_step: bad arguments");
-  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, NT * 4)), dim3(NT), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha, eps, wd);
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n, NT * 4)), dim3(NT), 0, (hipStream_t)stream, p, g, sq, n, lr, alpha, eps, wd,
+                     wd_mask);
   XR_CHECK_LAUNCH("xr_rmsprop_step");
   return XR_OK;
 }
 extern "C" int xr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                            float wd, int step, const void* tick, int64_t tick_ref, void* stream) {
+                            float wd, int step, const void* tick, int64_t tick_ref, const uint8_t* wd_mask, void* stream) {
   XR_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "xr_adam_step: bad arguments");
   const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, NT * 4)), dim3(NT), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, wd,
-                     bc1, bc2, step, (const uint64_t*)tick, (uint64_t)tick_ref);
+                     bc1, bc2, step, (const uint64_t*)tick, (uint64_t)tick_ref, wd_mask);
   XR_CHECK_LAUNCH("xr_adam_step");
   return XR_OK;
 }

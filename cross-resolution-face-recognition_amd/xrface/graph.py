@@ -11,6 +11,15 @@ forward, backward, optimizer update, BatchNorm counter bumps, weight re-packs --
 * dropout mixes a device-side step counter into its seed (``xr_dropout``'s ``tick``), incremented by the graph;
 * FusedAdam's bias corrections follow the same device counter; hyper-parameters passed by value (learning rate) are
   frozen: re-capture after changing them.  Steps taken by replays are not reflected in the optimizer's host-side counter.
+
+Replays change parameters and BatchNorm running statistics behind the host's back (no tensor version bump), so every
+replay invalidates the host-side caches keyed on them (weight packs, eval-mode BatchNorm coefficients): an eager
+evaluation between replays sees the current weights.
+
+Teardown is explicit: ``close()`` (also run by ``__del__``) first waits for the device -- a replay may still be in flight
+when the last reference dies, and destroying an executing graph or releasing its private memory pool under running
+kernels is undefined -- then drops the tensors that live in the graph's pool and only then resets the graph.  Every
+stream the capture touched is held for the lifetime of the object.
 """
 from __future__ import annotations
 
@@ -23,10 +32,14 @@ class GraphedStep:
     def __init__(self, fn, example_inputs, warmup: int = 3):
         """fn(*tensors) -> tensor | tuple of tensors | None runs one full step; it must not synchronise with the host."""
         assert all(t.is_cuda for t in example_inputs), "GraphedStep: inputs must be device tensors"
+        self.graph = None
+        self.static_out = None
         self.static_in = [t.clone() for t in example_inputs]
         dev = self.static_in[0].device if self.static_in else torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
         cur = torch.cuda.current_stream(dev)
         side = torch.cuda.Stream(dev)
+        self._streams = [cur, side]
         side.wait_stream(cur)
         with torch.cuda.stream(side):   # warm-up: lazy initialisation, weight-pack tables, allocator pools
             for _ in range(warmup):
@@ -37,21 +50,57 @@ class GraphedStep:
             ops._graph["tick"] = torch.zeros(1, dtype=torch.int64, device=dev)
         self.tick = ops._graph["tick"]
         ops._graph["tick_ref"] = int(self.tick.item()) + 1   # the value the first replay sees
-        self.graph = torch.cuda.CUDAGraph()
+        ops.join_side_stream()   # nothing of the warm-up may still be pending on the weight-gradient stream
+        graph = torch.cuda.CUDAGraph()
         ops._zpool.buf = None
         ops._graph["capturing"] = True
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(graph):
                 self.tick.add_(1)
                 self.static_out = fn(*self.static_in)
         finally:
             ops._graph["capturing"] = False
             ops._zpool.buf = None   # the slab captured above belongs to the graph's memory pool
+        self.graph = graph
 
     def __call__(self, *inputs):
         assert len(inputs) == len(self.static_in)
         for s, t in zip(self.static_in, inputs):
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t, non_blocking=True)
+        if self.graph is None:
+            raise RuntimeError("GraphedStep: called after close()")
         self.graph.replay()
+        ops.invalidate_weight_cache()   # the replay moved parameters / running statistics without bumping any version
         return self.static_out
+
+    def close(self):
+        """Release the captured graph and its private memory pool at a defined point (idempotent)."""
+        graph, self.graph = self.graph, None
+        if graph is None:
+            return
+        try:
+            torch.cuda.synchronize(self.device)   # no replay may be executing while its graph / pool goes away
+        except Exception:   # interpreter shutdown
+            pass
+        self.static_out = None                    # tensors allocated from the graph's pool go first
+        self.static_in = []
+        try:
+            graph.reset()
+        except Exception:
+            pass
+        del graph
+        self._streams = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

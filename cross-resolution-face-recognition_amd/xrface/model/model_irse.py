@@ -176,6 +176,12 @@ class Backbone(Module):
         emb, _ = self.f(enter(x))
         return leave2d(emb)
 
+    def parameters_in_execution_order(self):
+        """input_layer, body, output_layer -- the module registers output_layer BEFORE body (state_dict order of the
+        reference, model_irse.py:139-166).  parallel.FlatParams laid out in this order makes every gradient bucket a run of
+        layers that finish backward together, so the 51 MB Linear(25088, 512) bucket goes to RCCL at the START of backward."""
+        return [*self.input_layer.parameters(), *self.body.parameters(), *self.output_layer.parameters()]
+
     def forward_taps(self, x, taps=(2, 6, 20, 23)):
         """(emb, tap_0, ..) -- the 5-output teacher distill_main.py:59 unpacks (taps after the body blocks
         that end the four stages)."""

@@ -101,8 +101,19 @@ class batched_bn_counters:
 
 class _BNMixin:
     def _count(self):
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None and not _NBT_BATCHED[0]:
-            self.num_batches_tracked.add_(1)
+        if self.training and self.track_running_stats:
+            # the training forward rewrites running_mean / running_var through raw pointers (xr_norm_finalize): no tensor
+            # version changes, so the cached eval-mode coefficients are keyed on this counter as well
+            self.__dict__["_xr_stat_epoch"] = self.__dict__.get("_xr_stat_epoch", 0) + 1
+            if self.num_batches_tracked is not None and not _NBT_BATCHED[0]:
+                self.num_batches_tracked.add_(1)
+
+    def _momentum(self):
+        if self.momentum is None:
+            # torch's cumulative moving average (factor 1 / num_batches_tracked) needs the device-side counter on the host;
+            # the reference never uses it (every BatchNorm there keeps the default momentum 0.1)
+            raise NotImplementedError("xrface BatchNorm: momentum=None (cumulative average) is not supported")
+        return self.momentum
 
     def _eval_coef(self):
         """Eval mode: scale / shift depend only on the parameters and running statistics -- computed once per version of
@@ -111,7 +122,8 @@ class _BNMixin:
             return None
         tensors = (self.weight, self.bias, self.running_mean, self.running_var)
         key = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors) + (ops._pack_epoch[0],
-              self.weight.__dict__.get("_xr_epoch", 0) if self.weight is not None else 0)
+              self.weight.__dict__.get("_xr_epoch", 0) if self.weight is not None else 0,
+              self.__dict__.get("_xr_stat_epoch", 0))
         hit = self.__dict__.get("_xr_eval_coef")
         if hit is None or hit[0] != key:
             hit = (key, ops.bn_eval_coeffs(self.weight, self.bias, self.running_mean, self.running_var, self.eps))
@@ -121,7 +133,7 @@ class _BNMixin:
     def f(self, buf, res=None, act=None, alpha=None, slink=None):
         training = self.training or not self.track_running_stats
         self._count()
-        mom = 0.1 if self.momentum is None else self.momentum
+        mom = self._momentum()
         coef = None if training or torch.is_grad_enabled() and _any_requires_grad(self) else self._eval_coef()
         return ops.norm_act(buf, self.weight, self.bias, self.running_mean, self.running_var, res, alpha, "bn", act, training,
                             mom, self.eps, slink if training else None, coef)
@@ -133,7 +145,7 @@ class _BNMixin:
         link: an ops.BnLink shared with the one convolution that consumes bn(buf) (fused backward reduction)."""
         training = self.training or not self.track_running_stats
         self._count()
-        mom = 0.1 if self.momentum is None else self.momentum
+        mom = self._momentum()
         return ops.norm_act_pass(buf, self.weight, self.bias, self.running_mean, self.running_var, "bn", None, training, mom,
                                  self.eps, link if training else None)
 

@@ -86,10 +86,38 @@ def zeros_f32(shape, device):
     return _zpool.get(tuple(shape) if not isinstance(shape, int) else (shape,), device)
 
 
+# steps._pair_grads asks autograd for d loss_k / d theta_k only, but ``needs_input_grad`` of the custom Functions was fixed at
+# forward time: every backward the engine traverses would still compute (and, in direct mode, ACCUMULATE) the gradients of
+# parameters outside theta_k.  While a per-pair gradient is being taken this holds {id(p) for p in theta_k}: parameters
+# outside it get no weight-gradient launch and no in-place accumulation.
+_grad_only = [None]
+
+
+def _wanted(p):
+    s = _grad_only[0]
+    return s is None or id(p) in s
+
+
+class grad_only:
+    """Context: restrict parameter-gradient work of the HIP backward kernels to ``params``."""
+
+    def __init__(self, params):
+        self.ids = {id(p) for p in params}
+
+    def __enter__(self):
+        self.prev, _grad_only[0] = _grad_only[0], self.ids
+        return self
+
+    def __exit__(self, *exc):
+        _grad_only[0] = self.prev
+        return False
+
+
 def _direct(p):
     """Parameters re-pointed into a flat gradient buffer (parallel.FlatParams) take their gradient by in-kernel
     accumulation into ``p.grad`` -- no autograd AccumulateGrad add, no temporary.  Returns the target or None."""
-    if getattr(p, "_xr_direct", False) and p.grad is not None:
+    if getattr(p, "_xr_direct", False) and p.grad is not None and _wanted(p):
+        p.__dict__["_xr_touched"] = True
         return p.grad
     return None
 
@@ -478,11 +506,11 @@ class _Conv2d(Function):
                 link.deliver(dx, red)
         if dx is None and ctx.passthrough and _dp2 is not None:
             dx = _dp2
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _wanted(w):
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
-        if has_b and ctx.needs_input_grad[2]:
+        if has_b and ctx.needs_input_grad[2] and _wanted(ctx.bias_ref):
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db, None, None, None, None, None, None
 
@@ -527,14 +555,14 @@ class _ConvTranspose2d(Function):
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
                               kg, Cp, None, 0, None, None, None, 1, None, None, None, stream())
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _wanted(w):
             # dw[ci][co][r][s] = sum_{n,hi,wi} x[n,hi,wi,ci] * dy[n, hi*s - p + r, wi*s - p + s', co]: the weight gradient of an
             # ordinary strided convolution whose input is dy and whose output gradient is x -- rows = ci, cols = (tap, co),
             # forward gather (the fast incremental-cursor path) instead of a transposed gather of x
             kg = kg_of(R * S, Kp)
             dw = _wgrad(w, dy, x, N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0, Cp, kg,
                         _wgrad_split(N * H * W, Cin, kg), Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
-        if has_b and ctx.needs_input_grad[2]:
+        if has_b and ctx.needs_input_grad[2] and _wanted(ctx.bias_ref):
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, Cout))
         return dx, dw, db, None, None, None
 
@@ -585,10 +613,10 @@ class _LinearNHWC(Function):
             dx = torch.empty_like(x)
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
                               HW * C, None, 0, None, None, None, 1, None, None, None, stream())
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _wanted(w):
             kg = kg_of(HW, C)
             dw = _wgrad(w, x, dy, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, Kp, kg, 1, K, 1, HW, C, C, C * HW, 0, 1, HW)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if ctx.has_b and ctx.needs_input_grad[2] and _wanted(ctx.bias_ref):
             db = _emit_small(ctx.bias_ref, _bias_grad(dy, K))
         return dx, dw, db
 
@@ -654,7 +682,7 @@ class _PreluConv2d(Function):
                 _direct_done(alpha)
             else:
                 dalpha = dal
-        if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[2] and _wanted(w):
             kg = kg_of(R * S, Cp)
             dw = _wgrad(w, p1, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, Kp, kg, _wgrad_split(N * Ho * Wo, K, kg),
                         K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
@@ -1054,7 +1082,7 @@ class _BnSeAdd(Function):
             lib.xr_affine_act_bwd_apply(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(coef), ptr(dy), None, N, HW,
                                         C, 1, None, stream())
         dw1 = dw2 = None
-        if ctx.needs_input_grad[5]:
+        if ctx.needs_input_grad[5] and _wanted(w1):
             t1, t2 = _direct(w1), _direct(w2)
             dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), dev)
             dw2 = t2 if t2 is not None else zeros_f32((C, Cr, 1, 1), dev)
@@ -1079,7 +1107,7 @@ def bn_se_add(y, bn, se, shortcut):
     """bn: an xrface.nn.BatchNorm2d holder, se: a model_irse.SEModule holder."""
     training = bn.training or not bn.track_running_stats
     bn._count()
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    mom = bn._momentum()
     return _BnSeAdd.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, se.fc1.weight, se.fc2.weight, shortcut, training,
                           mom, bn.eps)
 
@@ -1266,12 +1294,40 @@ def dropout(x, p, training, mask=None, seed=None):
     return _Dropout.apply(x, float(p), mask, int(seed))
 
 
+class _GradScale(Function):
+    """Identity in forward; the gradient is multiplied by ``s`` on the way back (steps.fhn_step_fused: one backward pass
+    serves loss_k / theta_k pairs whose losses differ only by a constant factor)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        ctx.s = s
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.s, None
+
+
+def grad_scale(x, s):
+    return _GradScale.apply(x, float(s))
+
+
 def sub(a, b):
     return _AddSub.apply(a, b, -1)
 
 
 def add(a, b):
     return _AddSub.apply(a, b, 1)
+
+
+def sub_detached(a, b):
+    """(a - b).detach() for two same-layout activation tensors (the residual targets t_k - s_k of the KD step,
+    distill_main.py:68-70), one launch, no autograd node."""
+    with torch.no_grad():
+        a2, b2 = _same_layout(a.detach(), b.detach())
+        y = torch.empty_like(a2)
+        lib.xr_sub(dt(a2), ptr(a2), ptr(b2), ptr(y), a2.numel(), stream())
+    return y
 
 
 # ------------------------------------------------------------------------------------------------- losses

@@ -36,6 +36,30 @@ class FlatParams:
             p.data = v
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
             p._xr_direct = direct  # HIP backward kernels accumulate straight into p.grad (see ops._direct)
+            p.__dict__["_xr_touched"] = False
+            # gradients that arrive through autograd's AccumulateGrad (stock torch ops, direct=False) count as touched too
+            p.register_post_accumulate_grad_hook(_mark_touched)
+        self._mask_key = None
+        self._mask = None
+
+    def touched_mask(self, no_decay_ids=()):
+        """uint8 per element for the fused optimizers (xr_*_step ``wd_mask``): bit 0 = weight decay applies, bit 1 = the
+        parameter received no gradient since the last zero_grad() -> left untouched (a stock optimizer skips .grad None).
+        Returns None when every parameter was touched and none is decay-free.  Cached per touched-set."""
+        key = tuple(p.__dict__.get("_xr_touched", False) for p in self.params)
+        if key != self._mask_key:
+            self._mask_key = key
+            if all(key) and not no_decay_ids:
+                self._mask = None
+            else:
+                m = torch.ones(self.numel, dtype=torch.uint8)
+                for p, o, t in zip(self.params, self.offsets, key):
+                    if not t:
+                        m[o:o + p.numel()] = 2
+                    elif id(p) in no_decay_ids:
+                        m[o:o + p.numel()] = 0
+                self._mask = m.to(self.flat.device)
+        return self._mask
 
     def zero_grad(self):
         """One memset; .grad tensors stay allocated views (autograd accumulates in place)."""
@@ -43,17 +67,25 @@ class FlatParams:
         ops._side["cb"] = False   # a backward pass that raised never ran its end-of-backward callback: re-arm it
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):
+            p.__dict__["_xr_touched"] = False
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
                 p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+def _mark_touched(p):
+    p.__dict__["_xr_touched"] = True
 
 
 class BucketedAllReduce:
     """Average ``flat.grad`` across ranks in ~bucket_mb slices, each launched as soon as the last of its
     parameters has accumulated its gradient (reverse registration order ~ reverse execution order).
 
-    ``overlap=False`` defers every launch to ``finish()``: required when FlatParams(direct=True) is combined with a
-    model that applies one parameter at several sites (the shared FSRNet trunks), because the direct-accumulation
-    path signals per site, not per parameter."""
+    The direct-accumulation path (ops._direct_done) signals once per USE SITE of a parameter, not once per parameter (the
+    shared FSRNet trunks apply one parameter at nine sites).  The first step therefore only COUNTS the signals of every
+    parameter (all buckets are launched from ``finish()``); from the second step on a parameter is complete when its
+    count reaches the learned one, and a bucket is launched when all of its parameters are complete.  A parameter that
+    signals more often than learned after its bucket has gone out makes ``finish()`` raise (and re-learn) instead of
+    silently averaging incomplete gradients.  ``overlap=False`` defers every launch to ``finish()``."""
 
     def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True):
         self.flat = flat
@@ -79,6 +111,10 @@ class BucketedAllReduce:
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._hooks = []
+        self._expected = None                      # per-parameter signal counts of one step, learned in the first step
+        self._count = [0] * len(flat.params)
+        self._late = None
+        self.launch_order = []                     # bucket indices in the order they were launched this step (tests)
         self.enabled = self.world > 1
         if self.enabled and overlap:
             for i, p in enumerate(flat.params):
@@ -88,11 +124,16 @@ class BucketedAllReduce:
         self.reset()
 
     def reset(self):
-        self._pending = [len(idx) for (_, _, idx) in self.buckets]
+        exp = self._expected
+        self._pending = [sum(1 for i in idx if exp is None or exp[i] > 0) for (_, _, idx) in self.buckets]
+        self._count = [0] * len(self.flat.params)
+        self._launched = [False] * len(self.buckets)
         self._works = []
 
     def _launch(self, b):
         ops.join_side_stream()   # weight gradients computed on the side stream must have landed in the bucket
+        self._launched[b] = True
+        self.launch_order.append(b)
         lo, hi, _ = self.buckets[b]
         buf = self.flat.grad[lo:hi]
         if self.backend == "nccl":
@@ -103,18 +144,25 @@ class BucketedAllReduce:
 
     def _make_hook(self, i):
         def hook(_p):
+            self._count[i] += 1
+            exp = self._expected
+            if exp is None:            # first step: learn the per-parameter signal counts, launch from finish()
+                return
             b = self.bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:  # a parameter used at several sites may fire more than once: launch only once
-                self._launch(b)
+            if self._count[i] == exp[i]:
+                self._pending[b] -= 1
+                if self._pending[b] == 0:
+                    self._launch(b)
+            elif self._count[i] > exp[i] and self._launched[b]:
+                self._late = i         # more use sites than learned, and the bucket already went out
         return hook
 
     def finish(self):
         """Launch any bucket whose parameters never produced a gradient this step, then wait for all."""
         if not self.enabled:
             return
-        for b, left in enumerate(self._pending):
-            if left > 0:
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
                 self._launch(b)
         for w in self._works:
             if isinstance(w, tuple):
@@ -122,6 +170,17 @@ class BucketedAllReduce:
                 w[1].div_(self.world)
             else:
                 w.wait()
+        late = self._late
+        if self._expected is None and self._hooks:
+            self._expected = list(self._count)
+        self._late = None
+        self.last_launch_order, self.launch_order = self.launch_order, []
+        if late is not None:
+            self._expected = None     # re-learn on the next step
+            self.reset()
+            raise RuntimeError(f"BucketedAllReduce: parameter #{late} accumulated gradient at more sites than in the step the "
+                               "bucket schedule was learned from, after its bucket had been all-reduced; this step's "
+                               "averaged gradients are incomplete -- repeat the step (the schedule is being re-learned)")
         self.reset()
 
 
@@ -137,42 +196,64 @@ class _FlatOptimizer(torch.optim.Optimizer):
     """torch.optim.Optimizer subclass (schedulers / state_dict tooling keep working) that performs the whole
     update in one fused HIP launch over a FlatParams buffer."""
 
+    _STATE = ()   # names of the flat state buffers of the subclass
+
     def __init__(self, flat: FlatParams, defaults):
         self.flat = flat
         super().__init__(flat.params, defaults)
+        assert len(self.param_groups) == 1, "fused flat optimizers take ONE parameter group (hyper-parameters are per buffer)"
         self._steps = 0
+        self._nd = frozenset()
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
+
+    def _wd_mask(self):
+        return self.flat.touched_mask(self._nd)
+
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() plus the flat state buffers and the step count (momentum / second moments /
+        bias-correction step live outside ``self.state`` -- one buffer each, not one entry per parameter)."""
+        sd = super().state_dict()
+        sd["xr_flat"] = {"steps": self._steps, "numel": self.flat.numel,
+                         **{k: getattr(self, k).detach().clone() for k in self._STATE}}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fl = state_dict.pop("xr_flat", None)
+        super().load_state_dict(state_dict)
+        if fl is None:
+            raise RuntimeError("not a fused flat optimizer checkpoint (no 'xr_flat' entry): momentum would silently reset")
+        assert fl["numel"] == self.flat.numel, "checkpoint was written for a different parameter layout"
+        self._steps = int(fl["steps"])
+        for k in self._STATE:
+            getattr(self, k).copy_(fl[k])
 
 
 class FusedSGD(_FlatOptimizer):
     """torch.optim.SGD(momentum, weight_decay) semantics (DISTILLATION/train_HRN.py:75-84); ``no_decay`` lists
     parameters excluded from weight decay (the reference keeps BN parameters decay-free, :75-80)."""
+    _STATE = ("mom",)
 
     def __init__(self, flat, lr, momentum=0.9, weight_decay=0.0, no_decay=()):
         super().__init__(flat, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.mom = torch.zeros_like(flat.flat)
-        self.mask = None
-        nd = {id(p) for p in no_decay}
-        if nd and weight_decay != 0.0:
-            self.mask = torch.ones(flat.numel, dtype=torch.uint8, device=flat.flat.device)
-            for p, o in zip(flat.params, flat.offsets):
-                if id(p) in nd:
-                    self.mask[o:o + p.numel()] = 0
+        self._nd = frozenset(id(p) for p in no_decay) if weight_decay != 0.0 else frozenset()
 
     @torch.no_grad()
     def step(self, closure=None):
         ops.join_side_stream()   # no-op unless a backward pass ended without its end-of-backward join (e.g. it raised)
         g = self.param_groups[0]
         lib.xr_sgd_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.mom), self.flat.numel, g["lr"], g["momentum"],
-                        g["weight_decay"], ptr(self.mask), int(self._steps == 0), stream())
+                        g["weight_decay"], ptr(self._wd_mask()), int(self._steps == 0), stream())
         self._steps += 1
         ops.invalidate_weight_cache(self.flat.params)
 
 
 class FusedRMSprop(_FlatOptimizer):
     """torch.optim.RMSprop(alpha, eps, weight_decay) (Face_Hallucination_sub_Net.py:120-124)."""
+    _STATE = ("sq",)
 
     def __init__(self, flat, lr, alpha=0.99, eps=1e-8, weight_decay=0.0):
         super().__init__(flat, dict(lr=lr, alpha=alpha, eps=eps, weight_decay=weight_decay))
@@ -183,13 +264,14 @@ class FusedRMSprop(_FlatOptimizer):
         ops.join_side_stream()   # no-op unless a backward pass ended without its end-of-backward join (e.g. it raised)
         g = self.param_groups[0]
         lib.xr_rmsprop_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.sq), self.flat.numel, g["lr"], g["alpha"],
-                            g["eps"], g["weight_decay"], stream())
+                            g["eps"], g["weight_decay"], ptr(self._wd_mask()), stream())
         self._steps += 1
         ops.invalidate_weight_cache(self.flat.params)
 
 
 class FusedAdam(_FlatOptimizer):
     """torch.optim.Adam(betas, eps, weight_decay) (SUPER_RESOLUTION/train_FHN.py:115-121)."""
+    _STATE = ("m", "v")
 
     def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(flat, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
@@ -204,5 +286,6 @@ class FusedAdam(_FlatOptimizer):
         cap = ops._graph["capturing"]
         lib.xr_adam_step(ptr(self.flat.flat), ptr(self.flat.grad), ptr(self.m), ptr(self.v), self.flat.numel, g["lr"],
                          g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._steps,
-                         ptr(ops._graph["tick"]) if cap else None, ops._graph["tick_ref"] if cap else 0, stream())
+                         ptr(ops._graph["tick"]) if cap else None, ops._graph["tick_ref"] if cap else 0,
+                         ptr(self._wd_mask()), stream())
         ops.invalidate_weight_cache(self.flat.params)

@@ -4,6 +4,9 @@ section 0).  Pinned semantics: evaluate every forward once
 
   fhn_step      Face_Hallucination_sub_Net.py:218-247 loss->optimizer map on the 112x112 composition of
                 SUPER_RESOLUTION/train_FHN.py:274-279 (discriminator/MMD terms dropped: MMD is undefined upstream)
+  fhn_step_fused  the same four gradients from ONE backward pass (the map is linear in the losses)
+  gan_step      the same map on OverallNetwork_GAN at 224x224 with the discriminator / MMD terms kept
+  c4_step       BASELINE configs[3]: FHN -> IR-SE-50 student + assistant vs frozen IR-SE-50 teacher, residual-KD losses
   kd_step       distill_main.py:59-74 (the second student_optimizer.step() at :74 is a reference bug; the
                 assistant is stepped)
   teacher_step  train_teacher_model.py:189-202
@@ -18,13 +21,39 @@ from .loss.loss import CrossEntropyLoss, CrossEntropyLoss2d, MSELoss, MSELoss_La
 
 def _assign_grads(params, grads):
     for p, g in zip(params, grads):
+        if getattr(p, "_xr_direct", False):
+            # FlatParams: .grad is a view of the flat gradient buffer and stays one -- the HIP backward kernels accumulated
+            # into it in place (autograd then returns None); a tensor autograd did return is added into the view
+            if g is not None:
+                p.grad.add_(g)
+            continue
         p.grad = g  # None stays None: stock optimizers then skip the parameter (incl. weight decay)
 
 
-def _pair_grads(loss, module, retain=True):
-    params = [p for p in module.parameters() if p.requires_grad]
-    grads = torch.autograd.grad(loss, params, retain_graph=retain, allow_unused=True)
+def _pair_grads(loss, params, retain=True):
+    """d loss / d params at the current weights into ``.grad``.  ``needs_input_grad`` of the HIP Functions was fixed at
+    forward time, so the backward nodes this traversal crosses would also produce gradients of parameters OUTSIDE ``params``
+    (and, with FlatParams(direct=True), accumulate them in place): ops.grad_only restricts parameter-gradient work to
+    ``params`` -- no wasted weight-gradient launches, no foreign accumulation."""
+    if isinstance(params, torch.nn.Module):
+        params = params.parameters()
+    params = [p for p in params if p.requires_grad]
+    with ops.grad_only(params):
+        grads = torch.autograd.grad(loss, params, retain_graph=retain, allow_unused=True)
     _assign_grads(params, grads)
+
+
+def _zero_grads(modules, optimizers=None):
+    """Gradients of a step start from zero: fused flat optimizers zero their buffer (views stay), otherwise .grad = None."""
+    if optimizers is not None:
+        for o in (optimizers.values() if isinstance(optimizers, dict) else optimizers):
+            if o is not None:
+                o.zero_grad()
+        return
+    for m in modules:
+        for p in m.parameters():
+            if not getattr(p, "_xr_direct", False):
+                p.grad = None
 
 
 def fhn_step(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
@@ -49,6 +78,64 @@ def fhn_step(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
         for k in order:
             optimizers[k].step()
     outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach())
+    return {k: v.detach() for k, v in losses.items()}, outs
+
+
+def fhn_step_fused(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
+    """fhn_step's four (loss_k, theta_k) gradients from ONE backward pass.  The map is linear: the encoder and the decoder
+    both take 10 * d pix, the prior takes 1 * d pix + d landmark + d parsing, the coarse net only d(12 * mse97(coarse, hr))
+    -- so the prior / encoder see a detached coarse image, the pixel loss is back-propagated once with weight 10 and the
+    prior's branch re-scales it by 0.1 (ops.grad_scale).  3x forward FLOPs (SURVEY 8d's count for C3) instead of the five
+    partial traversals of the literal form; results agree with fhn_step to rounding (tests/test_gpu_models.py)."""
+    mse97, lmk_loss, ce2d = MSELossFunc(), MSELoss_Landmark(), CrossEntropyLoss2d()
+    order = ("coarse", "encoder", "prior", "decoder")
+    _zero_grads([nets[k] for k in order], optimizers)
+    _, coarse = nets["coarse"](lr_img)
+    c_in = coarse.detach()
+    pf, lmk, par = nets["prior"](c_in)
+    ef = nets["encoder"](c_in)
+    sr = nets["decoder"](torch.cat((ops.grad_scale(pf, 0.1), ef), 1))
+    pix = mse97(sr, hr_img)
+    l_coarse, l_lmk, l_par = 12.0 * mse97(coarse, hr_img), lmk_loss(lmk, heatmap), ce2d(par, parsing)
+    (l_coarse + 10.0 * pix + l_lmk + l_par).backward()
+    if optimizers is not None:
+        for k in order:
+            optimizers[k].step()
+    pix_d = pix.detach()
+    losses = {"coarse": l_coarse.detach(), "encoder": 10.0 * pix_d, "prior": pix_d + l_lmk.detach() + l_par.detach(),
+              "decoder": 10.0 * pix_d}
+    outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach())
+    return losses, outs
+
+
+def gan_step(model, lr_img, hr_img, heatmap, parsing, optimizers=None):
+    """Face_Hallucination_sub_Net.py:218-247 as written, on OverallNetwork_GAN (224x224 only, model/FSRnet.py:468) with the
+    discriminator terms kept: L_disc = -MMD(emb1, emb2) -> discriminator; L_coarse = 12*mse97(coarse, hr) -> coarse;
+    L_enc = 10*mse97(sr, hr) - L_disc -> encoder; L_prior = -L_disc + mse97(sr, hr) + lmk + CE -> prior;
+    L_dec = 10*mse97(sr, hr) -> decoder.  MMD is undefined upstream (build-defined, loss/loss.py:MMD; parity unpinned).
+    ``optimizers``: dict(disc, coarse, encoder, prior, decoder)."""
+    from .loss.loss import MMD
+    mse97, lmk_loss, ce2d = MSELossFunc(), MSELoss_Landmark(), CrossEntropyLoss2d()
+    sr, coarse, lmk, par, e1, e2 = model(lr_img, hr_img)
+    l_disc = -MMD(e1, e2)
+    pix = mse97(sr, hr_img)
+    losses = {
+        "disc": l_disc,
+        "coarse": 12.0 * mse97(coarse, hr_img),
+        "encoder": 10.0 * pix - l_disc,
+        "prior": -l_disc + pix + lmk_loss(lmk, heatmap) + ce2d(par, parsing),
+        "decoder": 10.0 * pix,
+    }
+    subnets = {"disc": model._discriminator, "coarse": model._coarse_sr_network, "encoder": model._fine_sr_encoder,
+               "prior": model._prior_estimation_network, "decoder": model._fine_sr_decoder}
+    order = ("disc", "coarse", "encoder", "prior", "decoder")
+    for i, k in enumerate(order):
+        _pair_grads(losses[k], subnets[k], retain=i + 1 < len(order))
+    if optimizers is not None:
+        for k in order:
+            optimizers[k].step()
+    outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach(), emb1=e1.detach(),
+                emb2=e2.detach())
     return {k: v.detach() for k, v in losses.items()}, outs
 
 
@@ -80,8 +167,7 @@ def fhn_perceptual_step(nets, backbone, lr_img, hr_img, heatmap, parsing, layer_
     l_ed = lam_feature * sum(mse(a, b) for a, b in zip(f_hr, f_sr))
     _pair_grads(l_coarse, nets["coarse"], retain=True)
     _pair_grads(l_prior, nets["prior"], retain=True)
-    params = [p for k in ("encoder", "decoder") for p in nets[k].parameters() if p.requires_grad]
-    _assign_grads(params, torch.autograd.grad(l_ed, params, allow_unused=True))
+    _pair_grads(l_ed, [p for k in ("encoder", "decoder") for p in nets[k].parameters()], retain=False)
     if optimizers is not None:
         for k in ("coarse", "prior", "encdec"):
             optimizers[k].step()
@@ -118,6 +204,43 @@ def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_op
     if assistant_optimizer is not None:
         assistant_optimizer.step()
     return (s_loss.detach(), a_loss.detach()), [v.detach() for v in s], [v.detach() for v in a], [v.detach() for v in t]
+
+
+def c4_step(fhn, student, assistant, teacher, lr_img, hr_img, optimizers=None, taps=(2, 6, 20, 23)):
+    """BASELINE configs[3]: the two halves of the system composed into one training step.
+    sr = FHN(lr) with the four generators composed as SUPER_RESOLUTION/train_FHN.py:274-279; the IR-SE-50 student and
+    assistant both see ``sr``, the frozen eval-mode IR-SE-50 teacher sees ``hr`` (5-output form distill_main.py:59 unpacks,
+    taps after body blocks 2/6/20/23); losses of distill_main.py:63-70.  Pinned (loss_k, theta_k) pairs at pre-step weights:
+      student_loss   = MSE(s_out, t_out)                                      -> student + the four FHN generators
+      assistant_loss = sum_k MSE(t_k - s_k, a_k) + MSE(t_out - s_out, a_out)  -> assistant
+    The two parameter sets are disjoint and the assistant's targets / input are detached, so ONE backward pass of
+    student_loss + assistant_loss yields exactly the two pair gradients (and is safe with FlatParams(direct=True)).
+    ``fhn``: dict(coarse, prior, encoder, decoder); ``optimizers`` (optional): iterable / dict of optimizers, all stepped.
+    Returns ((student_loss, assistant_loss), outputs dict)."""
+    crit = MSELoss()
+    teacher.eval()
+    student.train()
+    assistant.train()
+    _zero_grads([*fhn.values(), student, assistant], optimizers)
+    with torch.no_grad():
+        t = teacher.forward_taps(hr_img, taps)
+    _, coarse = fhn["coarse"](lr_img)
+    pf, _, _ = fhn["prior"](coarse)
+    ef = fhn["encoder"](coarse)
+    sr = fhn["decoder"](torch.cat((pf, ef), 1))
+    s = student.forward_taps(sr, taps)
+    a = assistant.forward_taps(sr.detach(), taps)
+    s_loss = crit(s[0], t[0])
+    a_loss = crit((t[0] - s[0]).detach(), a[0])
+    for k in range(1, 5):
+        a_loss = a_loss + crit(ops.sub_detached(t[k], s[k]), a[k])
+    (s_loss + a_loss).backward()
+    if optimizers is not None:
+        for o in (optimizers.values() if isinstance(optimizers, dict) else optimizers):
+            o.step()
+    outs = dict(sr=sr.detach(), coarse=coarse.detach(), s=[v.detach() for v in s], a=[v.detach() for v in a],
+                t=[v.detach() for v in t])
+    return (s_loss.detach(), a_loss.detach()), outs
 
 
 def teacher_step(model, x, target, optimizer=None, criterion=None):

@@ -46,16 +46,17 @@ def _rates(tp, fp, tn, fn, n):
 
 
 def calculate_accuracy(threshold, dist, actual_issame):
-    """reference utils/utils.py:14-24 (host arrays; kept for API compatibility)."""
-    predict_issame = np.less(dist, threshold)
-    tp = np.sum(np.logical_and(predict_issame, actual_issame))
-    fp = np.sum(np.logical_and(predict_issame, np.logical_not(actual_issame)))
-    tn = np.sum(np.logical_and(np.logical_not(predict_issame), np.logical_not(actual_issame)))
-    fn = np.sum(np.logical_and(np.logical_not(predict_issame), actual_issame))
-    tpr = 0 if (tp + fn == 0) else float(tp) / float(tp + fn)
-    fpr = 0 if (fp + tn == 0) else float(fp) / float(fp + tn)
-    acc = float(tp + tn) / dist.size
-    return tpr, fpr, acc
+    """(tpr, fpr, acc) at ONE threshold, predict_same = dist < threshold (reference utils/utils.py:14-24; host arrays).
+    Expressed through the same confusion counts the histogram path produces for a whole threshold grid."""
+    dist = np.asarray(dist)
+    same = np.asarray(actual_issame).astype(bool)
+    pred = dist < threshold
+    tp = np.array([np.count_nonzero(pred & same)])
+    fp = np.array([np.count_nonzero(pred & ~same)])
+    fn = np.array([np.count_nonzero(same)]) - tp
+    tn = np.array([np.count_nonzero(~same)]) - fp
+    tpr, fpr, acc = _rates(tp, fp, tn, fn, dist.size)
+    return float(tpr[0]), float(fpr[0]), float(acc[0])
 
 
 def calculate_roc(thresholds, embeddings1, embeddings2, actual_issame, nrof_folds=50, pca=0, fold_id=None):
@@ -98,26 +99,27 @@ def calculate_roc(thresholds, embeddings1, embeddings2, actual_issame, nrof_fold
 
 
 class AverageMeter(object):
-    """reference utils/utils.py:132-147."""
+    """Running mean of a scalar stream (reference utils/utils.py:132-147: attributes val / avg / sum / count,
+    methods reset() / update(val, n))."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
+        self.val, self.sum, self.count = 0, 0, 0
+
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0
 
     def update(self, val, n=1):
         self.val = val
-        self.sum += val * n
-        self.count += n
-        self.avg = self.sum / self.count
+        self.sum, self.count = self.sum + val * n, self.count + n
 
 
 def accuracy(output, target, topk=(1,)):
-    """reference utils/utils.py:156-169 (top-k precision; host-side bookkeeping)."""
-    maxk = max(topk)
-    batch_size = target.size(0)
-    _, pred = output.float().topk(maxk, 1, True, True)
-    pred = pred.t()
-    correct = pred.eq(target.view(1, -1).expand_as(pred))
-    return [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / batch_size) for k in topk]
+    """Top-k precision in percent, one 1-element tensor per k (reference utils/utils.py:156-169; host-side bookkeeping)."""
+    n = target.shape[0]
+    top = output.float().topk(max(topk), dim=1).indices            # (N, maxk), best first
+    hit = top.eq(target.reshape(-1, 1))                             # (N, maxk)
+    return [hit[:, :k].any(dim=1).float().sum().reshape(1) * (100.0 / n) for k in topk]

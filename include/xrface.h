@@ -268,13 +268,16 @@ int xr_l2norm_rows_bwd(const float* y, const float* inv_norm, const float* dy, f
  * Fused multi-tensor optimizers over flat fp32 buffers (torch.optim semantics):
  * SGD(momentum, weight_decay) DISTILLATION/train_HRN.py:75-84; RMSprop(alpha, eps, wd)
  * Face_Hallucination_sub_Net.py:120-124, distill_main.py:222-225; Adam(betas, eps, wd)
- * SUPER_RESOLUTION/train_FHN.py:115-121. `wd_mask` (optional, uint8 per element) disables decay. */
+ * SUPER_RESOLUTION/train_FHN.py:115-121.  `wd_mask` (optional, uint8 per element): bit 0 = apply weight decay (NULL: decay
+ * everywhere), bit 1 = skip the element entirely -- a parameter that received no gradient this step is left untouched,
+ * exactly as a stock torch.optim optimizer skips parameters whose .grad is None (bn_end, residual_next,
+ * ... must not start moving under weight decay). */
 int xr_sgd_step(float* p, const float* g, float* mom, int64_t n, float lr, float momentum, float wd,
                 const uint8_t* wd_mask, int first_step, void* stream);
 int xr_rmsprop_step(float* p, const float* g, float* sq, int64_t n, float lr, float alpha, float eps, float wd,
-                    void* stream);
+                    const uint8_t* wd_mask, void* stream);
 int xr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                 float wd, int step, const void* tick, int64_t tick_ref, void* stream);
+                 float wd, int step, const void* tick, int64_t tick_ref, const uint8_t* wd_mask, void* stream);
 /* `tick` (optional device uint64) / `tick_ref`: inside a captured HIP graph the effective step is
  * step + (*tick - tick_ref), so the bias corrections advance with the replays (see xr_dropout). */
 

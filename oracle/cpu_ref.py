@@ -23,6 +23,8 @@ Reference citations (relative to /root/reference):
   losses                    loss/loss.py:7-62
   pair distance + ROC       utils/utils.py:14-87
   KD step                   distill_main.py:42-96
+  C4 composed step          SUPER_RESOLUTION/train_FHN.py:274-279 + distill_main.py:59-70
+  LR synthesis / heat-maps  SUPER_RESOLUTION/FHN_loader.py:65-66,119-137
 """
 from __future__ import annotations
 
@@ -147,6 +149,46 @@ def fhn_forward(sds, lr_img):
     ef = fine_encoder(sds["encoder"], coarse_img)
     sr = fine_decoder(sds["decoder"], torch.cat((pf, ef), 1))
     return sr, coarse_img, lmk, par
+
+
+def discriminator(sd, x, train, new_stats=None, p=""):
+    """Discriminator.forward (model/FSRnet.py:477-485): conv3x3(192->64) -> bn_mid -> PReLU -> bn_mid AGAIN -> flatten ->
+    Linear(64*56*56 -> 512) -> BatchNorm1d.  ``bn_mid`` runs twice per call, so in train mode its running statistics are
+    updated twice (the second update starts from the first one's result)."""
+    ns = {} if new_stats is None else new_stats
+    cur = dict(sd)
+
+    def bn(key, t):
+        y = _bnorm(cur, key, t, train, ns)
+        if train:   # later uses of the same layer continue from the updated statistics
+            cur[key + ".running_mean"], cur[key + ".running_var"] = ns[key + ".running_mean"], ns[key + ".running_var"]
+        return y
+    y = F.prelu(bn(p + "bn_mid", _conv(sd, p + "conv_input", x, 1, 1)), sd[p + "relu.weight"])
+    y = bn(p + "bn_mid", y)
+    y = F.linear(y.flatten(1), sd[p + "fc.weight"], sd[p + "fc.bias"])
+    return bn(p + "bn_end", y)
+
+
+def gan_forward(sd, lr_img, hr_img, train):
+    """OverallNetwork_GAN.forward (model/FSRnet.py:525-545), 224x224 only: coarse -> forward_once(coarse) and
+    forward_once(hr) (encoder, prior, cat, discriminator) -> decoder(cat of the coarse branch).
+    Returns (sr, coarse, landmark1, parsing1, emb1, emb2, new discriminator running stats)."""
+    stats = {}
+    cur = dict(sd)
+    _, coarse = coarse_sr(sd, lr_img, "_coarse_sr_network.")
+
+    def once(x):
+        ef = fine_encoder(sd, x, "_fine_sr_encoder.")
+        pf, lmk, par = prior_net(sd, x, "_prior_estimation_network.")
+        cat = torch.cat((pf, ef), 1)
+        emb = discriminator(cur, cat, train, stats, "_discriminator.")
+        if train:
+            cur.update(stats)
+        return cat, lmk, par, emb
+    cat1, lmk1, par1, e1 = once(coarse)
+    _, _, _, e2 = once(hr_img)
+    sr = fine_decoder(sd, cat1, "_fine_sr_decoder.")
+    return sr, coarse, lmk1, par1, e1, e2, stats
 
 
 # ----------------------------------------------------------------------------- FSRNet (SR variant)
@@ -517,3 +559,33 @@ def fhn_perceptual_grads(sds, bb_sd, lr_img, hr_img, heatmap, parsing, taps=(21,
              "encoder": grads_of(l_ed, sds["encoder"], retain=True), "decoder": grads_of(l_ed, sds["decoder"], retain=True)}
     losses = dict(coarse=l_coarse.detach(), prior=l_prior.detach(), encdec=l_ed.detach())
     return losses, dict(coarse=coarse.detach(), sr=sr.detach()), grads
+
+
+def c4_step_grads(fhn_sds, s_sd, a_sd, t_sd, lr_img, hr_img, taps=IR50_STAGE_ENDS):
+    """BASELINE config 4: the two halves composed.  sr = FHN(lr) with the four root generators composed
+    as SUPER_RESOLUTION/train_FHN.py:274-279; IR-SE-50 student and assistant (train mode, Dropout pinned off) both see
+    ``sr``; the frozen eval-mode IR-SE-50 teacher sees ``hr``; losses of distill_main.py:63-70 with the stage taps
+    after body blocks 2/6/20/23.  Pinned (loss_k, theta_k) pairs at pre-step weights:
+      student_loss   = MSE(s_out, t_out)                                        -> student AND the four FHN generators
+                                                                                   (the gradient flows through the student
+                                                                                   into the hallucination net)
+      assistant_loss = sum_k MSE(t_k - s_k, a_k) + MSE(t_out - s_out, a_out)    -> assistant
+    Returns ((s_loss, a_loss), outputs dict, grads dict(student, assistant, coarse, prior, encoder, decoder), stats)."""
+    with torch.no_grad():
+        t = ir_teacher5(t_sd, hr_img, se=True)
+    fhn = {k: with_grad(v) for k, v in fhn_sds.items()}
+    s_sd, a_sd = with_grad(s_sd), with_grad(a_sd)
+    sr, coarse, lmk, par = fhn_forward(fhn, lr_img)
+    st_s, st_a = {}, {}
+    s_e, s_t = ir_backbone(s_sd, sr, se=True, train=True, taps=taps, new_stats=st_s)
+    a_e, a_t = ir_backbone(a_sd, sr, se=True, train=True, taps=taps, new_stats=st_a)
+    s, a = (s_e, *s_t), (a_e, *a_t)
+    s_loss = F.mse_loss(s[0], t[0])
+    a_loss = sum(F.mse_loss(t[k] - s[k], a[k]) for k in range(1, 5)) + F.mse_loss(t[0] - s[0], a[0])
+    grads = {"student": grads_of(s_loss, s_sd, retain=True)}
+    for k in ("coarse", "prior", "encoder", "decoder"):
+        grads[k] = grads_of(s_loss, fhn[k], retain=True)
+    grads["assistant"] = grads_of(a_loss, a_sd)
+    outs = dict(sr=sr.detach(), coarse=coarse.detach(), s_emb=s[0].detach(), a_emb=a[0].detach(), t_emb=t[0],
+                s_taps=[v.detach() for v in s[1:]], a_taps=[v.detach() for v in a[1:]], t_taps=list(t[1:]))
+    return (s_loss.detach(), a_loss.detach()), outs, grads, (st_s, st_a)

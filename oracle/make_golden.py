@@ -88,13 +88,7 @@ def compare_grads(gref, gmine, what, store=None, prefix="", keep=()):
     return worst
 
 
-def main():
-    torch.manual_seed(0)
-    torch.set_num_threads(8)
-    os.makedirs(OUT, exist_ok=True)
-    keys = {}
-    t0 = time.time()
-
+def sec_fsrnet_root(keys, t0):
     # ------------------------------------------------------------------ FSRNet root (a1-a6, a14, a16)
     fsr = ref_import("model.FSRnet")
     loss_mod = ref_import("loss.loss")
@@ -162,7 +156,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fsrnet_root.npz"), **st)
     print(f"[golden] fsrnet_root ok ({time.time() - t0:.1f}s)")
 
+
+
+def sec_fsrnet_sr(keys, t0):
     # ------------------------------------------------------------------ FSRNet SR variant (a8, a9)
+    loss_mod = ref_import("loss.loss")
     fsr_sr = ref_import("SUPER_RESOLUTION.model.FSRnet")
     st = {}
     hr1 = G.synth_faces(1, 112, seed=1, start=400)
@@ -194,6 +192,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "fsrnet_sr.npz"), **st)
     print(f"[golden] fsrnet_sr ok ({time.time() - t0:.1f}s)")
 
+
+
+def sec_irse(keys, t0):
     # ------------------------------------------------------------------ IR-50 / IR-SE-50 (a10, a11, a13, a19)
     irse = ref_import("SUPER_RESOLUTION.model.model_irse")
     gdc = ref_import("SUPER_RESOLUTION.model.GroupDepthConv")
@@ -237,7 +238,12 @@ def main():
         print(f"[golden] {tag} ok ({time.time() - t0:.1f}s)")
     np.savez_compressed(os.path.join(OUT, "irse.npz"), **st)
 
+
+
+def sec_resnet_kd(keys, t0):
     # ------------------------------------------------------------------ ResNet-34 + KD step (a12, a18)
+    irse = ref_import("SUPER_RESOLUTION.model.model_irse")
+    gdc = ref_import("SUPER_RESOLUTION.model.GroupDepthConv")
     resnet = ref_import("model.resnet")
     st = {}
     x = G.synth_faces(8, 112, seed=1, start=200)
@@ -277,7 +283,11 @@ def main():
     np.savez_compressed(os.path.join(OUT, "resnet_kd.npz"), **st)
     print(f"[golden] resnet34 + kd ok ({time.time() - t0:.1f}s)")
 
+
+
+def sec_losses_roc(keys, t0):
     # ------------------------------------------------------------------ losses (a14)
+    loss_mod = ref_import("loss.loss")
     st = {}
     a_ = torch.from_numpy(G.normal("loss/a", 2 * 3 * 16 * 16).reshape(2, 3, 16, 16).astype(np.float32))
     b_ = torch.from_numpy(G.normal("loss/b", 2 * 3 * 16 * 16).reshape(2, 3, 16, 16).astype(np.float32))
@@ -322,10 +332,141 @@ def main():
                         fold_id=fold_id, dist=uu.np.sum(np.square(e1 - e2), 1), p=np.int64(p))
     print(f"[golden] losses + roc ok ({time.time() - t0:.1f}s)")
 
-    with open(os.path.join(OUT, "state_dict_keys.json"), "w") as f:
+
+
+def _taps5(gdc, net, x, keys=("2", "6", "20", "23")):
+    """(emb, t1..t4) of a reference IR backbone through the reference's own FeatureExtractor (GroupDepthConv.py:35-45)."""
+    feats, _, last, _ = gdc.FeatureExtractor()(net.input_layer(x), list(keys), net.body)
+    return (net.output_layer(last), *[feats[k] for k in keys])
+
+
+def sec_c4(keys, t0):
+    # ------------------------------------------------------------------ C4 composed step (BASELINE configs[3], SURVEY 8d)
+    fsr = ref_import("model.FSRnet")
+    irse = ref_import("SUPER_RESOLUTION.model.model_irse")
+    gdc = ref_import("SUPER_RESOLUTION.model.GroupDepthConv")
+    st = {}
+    n = 4
+    hr = G.synth_faces(n, 112, seed=1, start=600)
+    lr = G.synth_lr_from_hr(hr)
+    nets = dict(coarse=fsr.Course_SR_Network(), encoder=fsr.Fine_SR_Encoder(),
+                prior=fsr.Prior_Estimation_Network(), decoder=fsr.Fine_SR_Decoder())
+    sds = {k: load_det(m, 5) for k, m in nets.items()}
+    teacher = irse.IR_SE_50([112, 112]); t_sd = load_det(teacher, 0); teacher.eval()
+    student = irse.IR_SE_50([112, 112]); s_sd = load_det(student, 1); student.train()
+    assistant = irse.IR_SE_50([112, 112]); a_sd = load_det(assistant, 2); assistant.train()
+    student.output_layer[1].p = 0.0       # Dropout RNG pinned off
+    assistant.output_layer[1].p = 0.0
+    # composition of SUPER_RESOLUTION/train_FHN.py:274-279 followed by distill_main.py:59-70
+    _, coarse = nets["coarse"](lr)
+    pf, lmk, prs = nets["prior"](coarse)
+    ef = nets["encoder"](coarse)
+    sr = nets["decoder"](torch.cat((pf, ef), 1))
+    with torch.no_grad():
+        t = _taps5(gdc, teacher, hr)
+    s = _taps5(gdc, student, sr)
+    a = _taps5(gdc, assistant, sr)
+    crit = torch.nn.MSELoss()
+    s_loss = crit(s[0], t[0].detach())
+    a_loss = crit(t[1] - s[1], a[1]) + crit(t[2] - s[2], a[2]) + crit(t[3] - s[3], a[3]) + crit(t[4] - s[4], a[4]) \
+        + crit(t[0] - s[0], a[0])
+    (sl, al), outs, g, stats = R.c4_step_grads(sds, s_sd, a_sd, t_sd, lr, hr)
+    close(outs["sr"], sr, "c4 sr"); close(outs["s_emb"], s[0], "c4 student emb"); close(outs["a_emb"], a[0], "c4 assistant emb")
+    close(outs["t_emb"], t[0], "c4 teacher emb")
+    for i in range(4):
+        close(outs["s_taps"][i], s[1 + i], f"c4 student tap {i}"); close(outs["a_taps"][i], a[1 + i], f"c4 assistant tap {i}")
+    close(sl, s_loss, "c4 student loss", 1e-5); close(al, a_loss, "c4 assistant loss", 1e-5)
+    pack(st, "sr", sr); pack(st, "s_emb", s[0]); pack(st, "a_emb", a[0]); pack(st, "t_emb", t[0])
+    pack(st, "s_tap3", s[4]); pack(st, "a_tap0", a[1])
+    st["student_loss"] = np.float64(s_loss.item()); st["assistant_loss"] = np.float64(a_loss.item())
+    keep = dict(student=("input_layer.0.weight", "body.0.res_layer.1.weight", "body.7.res_layer.5.fc1.weight",
+                         "body.23.res_layer.4.weight", "output_layer.3.bias", "output_layer.4.weight"),
+                assistant=("input_layer.0.weight", "body.3.shortcut_layer.0.weight", "body.20.res_layer.3.weight",
+                           "output_layer.4.weight"),
+                coarse=("conv_input.weight", "residual.2.conv1.weight", "conv_mid.weight"),
+                encoder=("conv_input.weight", "conv_end.weight"),
+                prior=("conv.weight", "hg.hg.1.0.0.conv1.weight"),
+                decoder=("conv_input.weight", "deconv.weight", "conv_out.weight", "bn_mid.weight"))
+    mods = dict(student=student, assistant=assistant, **nets)
+    for k in ("student", "coarse", "prior", "encoder", "decoder"):
+        compare_grads(grads_ref(s_loss, mods[k], retain=True), g[k], f"c4 {k}", st, f"{k}/", keep[k])
+    compare_grads(grads_ref(a_loss, assistant, retain=True), g["assistant"], "c4 assistant", st, "assistant/", keep["assistant"])
+    new_sd = student.state_dict()
+    for k in ("input_layer.1.running_mean", "body.23.res_layer.4.running_var"):
+        close(stats[0][k], new_sd[k], f"c4 student {k}")
+        pack(st, f"student/stats/{k}", new_sd[k])
+    np.savez_compressed(os.path.join(OUT, "c4.npz"), **st)
+    print(f"[golden] c4 ok ({time.time() - t0:.1f}s)")
+
+
+def sec_gan(keys, t0):
+    # ------------------------------------------------------------------ OverallNetwork_GAN + Discriminator @224 (a7, f4)
+    fsr = ref_import("model.FSRnet")
+    st = {}
+    n = 3
+    hr = G.synth_faces(n, 224, seed=1, start=700)
+    lr = G.synth_lr_from_hr(hr)
+    net = fsr.OverallNetwork_GAN()
+    sd = load_det(net, 7)
+    keys["fsrnet_root.gan"] = {k: list(v.shape) for k, v in net.state_dict().items()}
+    net.train()
+    sr, coarse, lmk, prs, e1, e2 = net(lr, hr)
+    m_sr, m_coarse, m_lmk, m_prs, m_e1, m_e2, stats = R.gan_forward(sd, lr, hr, train=True)
+    for nm, a_, b_ in (("sr", m_sr, sr), ("coarse", m_coarse, coarse), ("landmark", m_lmk, lmk), ("parsing", m_prs, prs),
+                       ("emb1", m_e1, e1), ("emb2", m_e2, e2)):
+        close(a_, b_, "gan train " + nm, 5e-4)
+        pack(st, "train/" + nm, b_)
+    # one pinned adversarial-style pair: L_d = MSE(emb1, emb2) -> discriminator (MMD itself is undefined upstream)
+    l_d = F.mse_loss(e1, e2)
+    g_ref = grads_ref(l_d, net._discriminator, retain=True)
+    sdg = R.with_grad(sd)
+    o = R.gan_forward(sdg, lr, hr, train=True)
+    g_m = R.grads_of(F.mse_loss(o[4], o[5]), {k[len("_discriminator."):]: v for k, v in sdg.items()
+                                              if k.startswith("_discriminator.")})
+    compare_grads(g_ref, g_m, "gan disc", st, "disc/", keep=("conv_input.weight", "bn_mid.weight", "fc.weight", "fc.bias",
+                                                              "bn_end.weight"))
+    st["disc/loss"] = np.float64(l_d.item())
+    new_sd = net.state_dict()
+    for k in ("_discriminator.bn_mid.running_mean", "_discriminator.bn_mid.running_var", "_discriminator.bn_end.running_var"):
+        close(stats[k], new_sd[k], "gan " + k)
+        pack(st, "train/stats/" + k, new_sd[k])
+    st["train/nbt"] = np.int64(int(new_sd["_discriminator.bn_mid.num_batches_tracked"]))
+    net.eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        outs = net(lr[:2], hr[:2])
+        mine = R.gan_forward(sd, lr[:2], hr[:2], train=False)
+    for nm, a_, b_ in zip(("sr", "coarse", "landmark", "parsing", "emb1", "emb2"), mine[:6], outs):
+        close(a_, b_, "gan eval " + nm, 5e-4)
+        pack(st, "eval/" + nm, b_)
+    np.savez_compressed(os.path.join(OUT, "gan224.npz"), **st)
+    print(f"[golden] gan224 ok ({time.time() - t0:.1f}s)")
+
+
+SECTIONS = {}   # filled below main's helpers (name -> function), in generation order
+
+
+def main(argv):
+    """python oracle/make_golden.py [section ...]   (no argument: every section)"""
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(OUT, exist_ok=True)
+    t0 = time.time()
+    names = argv or list(SECTIONS)
+    kpath = os.path.join(OUT, "state_dict_keys.json")
+    keys = {}
+    if argv and os.path.exists(kpath):      # partial run: keep the other sections' key dumps
+        with open(kpath) as f:
+            keys = json.load(f)
+    for nm in names:
+        SECTIONS[nm](keys, t0)
+    with open(kpath, "w") as f:
         json.dump(keys, f, indent=0, sort_keys=True)
     print(f"[golden] wrote fixtures to {OUT} in {time.time() - t0:.1f}s")
 
 
+SECTIONS.update(fsrnet_root=sec_fsrnet_root, fsrnet_sr=sec_fsrnet_sr, irse=sec_irse, resnet_kd=sec_resnet_kd,
+                losses_roc=sec_losses_roc, c4=sec_c4, gan=sec_gan)
+
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -36,6 +36,7 @@ def test_argument_validation_without_gpu():
     ("fsrnet_root.encoder", "xrface.model.FSRnet:Fine_SR_Encoder"),
     ("fsrnet_root.prior", "xrface.model.FSRnet:Prior_Estimation_Network"),
     ("fsrnet_root.decoder", "xrface.model.FSRnet:Fine_SR_Decoder"),
+    ("fsrnet_root.gan", "xrface.model.FSRnet:OverallNetwork_GAN"),
     ("ir50", "xrface.model.model_irse:IR_50"),
     ("irse50", "xrface.model.model_irse:IR_SE_50"),
     ("resnet34", "xrface.model.resnet:ResNet_34"),

@@ -1,20 +1,11 @@
 """GPU: whole-step HIP graphs (xrface.graph.GraphedStep) reproduce the eager step."""
 import copy
-import gc
 
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-
-
-@pytest.fixture(autouse=True)
-def _release_graphs():
-    """Destroy captured graphs (and their private memory pools) at a defined point, not whenever the cyclic GC gets to them."""
-    yield
-    gc.collect()
-    torch.cuda.synchronize()
 
 
 def _rel(a, b):
@@ -219,7 +210,89 @@ def test_graph_capture_with_side_stream_enabled():
         for _ in range(20):
             last = float(gs(x))
         assert last == last and last < first     # still training on the fixed batch
-        del gs
+        gs.close()
+        with pytest.raises(RuntimeError, match="after close"):
+            gs(x)
     finally:
         ops._cfg["wgrad_stream"] = old
         xrface.set_compute_dtype(torch.float32)
+
+
+def test_eval_between_replays_sees_current_weights_and_statistics():
+    """train/validate loop around a captured step: replays move the parameters and the BatchNorm running statistics without
+    bumping any tensor version, so the host-side caches (weight packs, eval-mode BatchNorm scale/shift) must be invalidated
+    by the replay itself -- an eval forward after N replays equals the eval forward of an eager twin after N eager steps,
+    and differs from the eval forward taken before them."""
+    import xrface
+    from xrface import parallel
+    from xrface.graph import GraphedStep
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model.resnet import ResNet_34
+
+    xrface.set_compute_dtype(torch.float32)
+    torch.manual_seed(5)
+    m_e = ResNet_34().to(DEV).train()
+    m_g = copy.deepcopy(m_e)
+    crit = CrossEntropyLoss()
+    y = torch.randint(0, 512, (8,), device=DEV)
+    x, xv = _faces(8, 3), _faces(4, 9)
+
+    def make(model):
+        flat = parallel.FlatParams(model.parameters())
+        opt = parallel.FusedSGD(flat, lr=0.02, momentum=0.9)
+        buf = torch.zeros((), device=DEV)
+
+        def step(xin):
+            opt.zero_grad()
+            loss = crit(model(xin)[0], y)
+            loss.backward()
+            opt.step()
+            buf.copy_(loss.detach())
+            return buf
+        return step
+
+    def validate(model):
+        model.eval()
+        with torch.no_grad():
+            e = model(xv)[0].float().clone()
+        model.train()
+        return e
+
+    step_e, step_g = make(m_e), make(m_g)
+    for _ in range(2):
+        step_e(x)
+    with GraphedStep(step_g, [x], warmup=2) as gs:
+        v0_e, v0_g = validate(m_e), validate(m_g)          # fills the eval caches (packs + BatchNorm coefficients)
+        assert _rel(v0_g, v0_e) < 3e-2
+        for _ in range(4):
+            step_e(x)
+            gs(x)
+        v1_e, v1_g = validate(m_e), validate(m_g)
+        torch.cuda.synchronize()
+        assert _rel(v1_e, v0_e) > 1e-2, "the twin's weights did not move: the test would prove nothing"
+        assert _rel(v1_g, v1_e) < 5e-2, "eval after replays must use the replayed weights / running statistics"
+        assert _rel(v1_g, v0_g) > 1e-2, "stale eval caches: the eval forward did not change across 4 replays"
+
+
+def test_eval_coefficients_follow_running_statistics_in_eager_mode():
+    """Eager mode: a train-mode forward rewrites running_mean / running_var through raw pointers (no version bump);
+    the next eval forward must not reuse scale/shift cached from the older statistics."""
+    import xrface
+    from xrface import nn as xnn
+
+    xrface.set_compute_dtype(torch.float32)
+    bn = xnn.BatchNorm2d(16).to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(4, 16, 8, 8, device=DEV, generator=g) * 3 + 2
+    bn.eval()
+    with torch.no_grad():
+        y0 = bn(x).clone()
+    bn.train()
+    with torch.no_grad():
+        bn(x)
+    bn.eval()
+    with torch.no_grad():
+        y1 = bn(x).clone()
+    ref = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.1, bn.eps)
+    assert _rel(y1, ref) < 1e-5
+    assert _rel(y1, y0) > 1e-2

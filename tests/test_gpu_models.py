@@ -395,3 +395,269 @@ def test_fhn_perceptual_step_matches_oracle():
         cos = float((a @ b) / (a.norm() * b.norm()))
         print(f"[prior] gradient cosine similarity vs oracle: {cos:.5f} (worst tensor {wname}: {worst:.2e})")
         assert cos > 0.98, cos
+
+
+# ---------------------------------------------------------------------------------------------------------------- C4
+def _c4_nets(dtype_seed=5):
+    from xrface.model import FSRnet, model_irse
+    fhn, fhn_sd = {}, {}
+    for k, ctor in (("coarse", FSRnet.Course_SR_Network), ("encoder", FSRnet.Fine_SR_Encoder),
+                    ("prior", FSRnet.Prior_Estimation_Network), ("decoder", FSRnet.Fine_SR_Decoder)):
+        fhn[k], fhn_sd[k] = load_det(ctor(), 5)
+    teacher, t_sd = load_det(model_irse.IR_SE_50([112, 112]), 0)
+    student, s_sd = load_det(model_irse.IR_SE_50([112, 112]), 1)
+    assistant, a_sd = load_det(model_irse.IR_SE_50([112, 112]), 2)
+    for m in (student, assistant):
+        m.output_layer[1].p = 0.0      # Dropout RNG pinned off, as in the fixture
+    for p_ in teacher.parameters():
+        p_.requires_grad_(False)
+    return fhn, student, assistant, teacher, (fhn_sd, s_sd, a_sd, t_sd)
+
+
+def _check_prefixed_grads(st, prefix, module, tol):
+    g = grads_by_name(module)
+    pre = prefix + "grad/"
+    floor = grad_floor(st, pre)
+    for key in st.files:
+        if key.startswith(pre):
+            name = key[len(pre):].replace("@digest", "")
+            check_against(st, pre + name, g[name], tol, floor=floor)
+    none_ref = set(st[prefix + "none_grad_keys"].tolist())
+    got_none = {n for n, p in module.named_parameters() if p.grad is None}
+    assert got_none == none_ref, (prefix, got_none ^ none_ref)
+
+
+def test_c4_composed_step_matches_reference_fixture():
+    """BASELINE configs[3] (north-star headline workload): FHN -> IR-SE-50 student + assistant vs the frozen IR-SE-50 teacher,
+    residual-KD losses.  fp32 parity mode, N = 4 (the fixture's batch, generated from the reference's own modules composed as
+    SUPER_RESOLUTION/train_FHN.py:274-279 + distill_main.py:59-70): SR image, embeddings, taps and both losses within 1e-3;
+    student / assistant / four-generator gradients and the .grad-is-None sets."""
+    import xrface
+    from xrface.steps import c4_step
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("c4.npz")
+    fhn, student, assistant, teacher, _ = _c4_nets()
+    hr = G.synth_faces(4, 112, seed=1, start=600)
+    lr = G.synth_lr_from_hr(hr)
+    (sl, al), outs = c4_step(fhn, student, assistant, teacher, lr.to(DEV), hr.to(DEV))
+    check_against(st, "sr", outs["sr"], TOL)
+    check_against(st, "t_emb", outs["t"][0], TOL)
+    check_against(st, "s_emb", outs["s"][0], TOL)
+    check_against(st, "a_emb", outs["a"][0], TOL)
+    check_against(st, "s_tap3", outs["s"][4], TOL)
+    check_against(st, "a_tap0", outs["a"][1], TOL)
+    for got, key in ((sl, "student_loss"), (al, "assistant_loss")):
+        ref = float(st[key])
+        assert abs(got.item() - ref) <= TOL * abs(ref), (key, got.item(), ref)
+    _check_prefixed_grads(st, "student/", student, KD_GRAD_TOL)
+    _check_prefixed_grads(st, "assistant/", assistant, KD_GRAD_TOL)
+    for k in ("coarse", "prior", "encoder", "decoder"):
+        _check_prefixed_grads(st, k + "/", fhn[k], KD_GRAD_TOL)
+    new_sd = student.state_dict()
+    for k in ("input_layer.1.running_mean", "body.23.res_layer.4.running_var"):
+        check_against(st, f"student/stats/{k}", new_sd[k], TOL)
+    assert all(p_.grad is None for p_ in teacher.parameters())
+
+
+def test_c4_flat_direct_mode_equals_plain_autograd():
+    """The benchmarked form of the C4 step (FlatParams with in-kernel gradient accumulation + side-stream weight gradients +
+    fused optimizers) produces the same gradients as the plain-autograd form checked against the fixture above, keeps the
+    parameters that receive no gradient (prior heads, bn_end, residual_next ...) bit-identical through an optimizer step
+    with weight decay, and moves the others."""
+    import xrface
+    from xrface import parallel
+    from xrface.steps import c4_step
+    xrface.set_compute_dtype(torch.float32)
+    hr = G.synth_faces(4, 112, seed=1, start=600)
+    lr = G.synth_lr_from_hr(hr)
+    fhn, student, assistant, teacher, _ = _c4_nets()
+    c4_step(fhn, student, assistant, teacher, lr.to(DEV), hr.to(DEV))
+    ref = {}
+    for tag, m in (("student", student), ("assistant", assistant), *fhn.items()):
+        ref[tag] = {n: (None if p_.grad is None else p_.grad.clone()) for n, p_ in m.named_parameters()}
+    fhn2, student2, assistant2, teacher2, _ = _c4_nets()
+    fhn_params = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn2[k].parameters()]
+    flats = [parallel.FlatParams(fhn_params), parallel.FlatParams(student2.parameters()), parallel.FlatParams(assistant2.parameters())]
+    opts = [parallel.FusedRMSprop(flats[0], lr=1e-4, alpha=0.99, weight_decay=1e-5),
+            parallel.FusedSGD(flats[1], lr=1e-3, momentum=0.9, weight_decay=1e-4),
+            parallel.FusedSGD(flats[2], lr=1e-3, momentum=0.9, weight_decay=1e-4)]
+    before = [f.flat.clone() for f in flats]
+    # gradients first (no optimizer step): compare with the plain-autograd run
+    c4_step(fhn2, student2, assistant2, teacher2, lr.to(DEV), hr.to(DEV), optimizers=None)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for tag, m in (("student", student2), ("assistant", assistant2), *fhn2.items()):
+        scale = max(float(g.abs().max()) for g in ref[tag].values() if g is not None)
+        for n, p_ in m.named_parameters():
+            g_ref = ref[tag][n]
+            if g_ref is None:
+                assert float(p_.grad.abs().max()) == 0.0 and not p_.__dict__.get("_xr_touched", False), (tag, n)
+                continue
+            assert p_.__dict__.get("_xr_touched", False), (tag, n)
+            err = float((p_.grad - g_ref).abs().max()) / max(float(g_ref.abs().max()), 1e-2 * scale)
+            worst = max(worst, err)
+            assert err < 1e-2, (tag, n, err)     # bar: the path's own run-to-run spread (fp32 atomics order x small-batch norms)
+    print(f"[c4 direct] worst gradient deviation from the plain-autograd form: {worst:.2e}")
+    # now a full step with the optimizers: untouched parameters must not move (weight decay included)
+    c4_step(fhn2, student2, assistant2, teacher2, lr.to(DEV), hr.to(DEV), optimizers=opts)
+    torch.cuda.synchronize()
+    for f, b in zip(flats, before):
+        for p_, o in zip(f.params, f.offsets):
+            seg_new, seg_old = f.flat[o:o + p_.numel()], b[o:o + p_.numel()]
+            if p_.__dict__.get("_xr_touched", False):
+                assert not torch.equal(seg_new, seg_old)
+            else:
+                assert torch.equal(seg_new, seg_old), "a parameter without gradient moved (weight decay on an unused parameter)"
+
+
+def test_c4_full_size_bf16_properties():
+    """C4 at BASELINE's per-GPU batch (256, bf16, every fused path and the side stream on): size-independent properties.
+    (1) the step is repeatable: same losses, gradient cosine > 0.995 between two runs; (2) the bf16 losses agree with the fp32
+    parity mode on a 64-image slice of the same batch (the parity mode is pinned to the reference fixture at N = 4);
+    (3) three optimizer steps on a fixed batch reduce the student loss."""
+    import xrface
+    from xrface import parallel
+    from xrface.model import FSRnet, model_irse
+    from xrface.steps import c4_step
+    torch.manual_seed(31)
+    mk = lambda: {"coarse": FSRnet.Course_SR_Network().to(DEV), "prior": FSRnet.Prior_Estimation_Network().to(DEV),
+                  "encoder": FSRnet.Fine_SR_Encoder().to(DEV), "decoder": FSRnet.Fine_SR_Decoder().to(DEV)}
+    fhn = mk()
+    student, assistant = model_irse.IR_SE_50([112, 112]).to(DEV), model_irse.IR_SE_50([112, 112]).to(DEV)
+    teacher = model_irse.IR_SE_50([112, 112]).to(DEV).eval()
+    for m in (student, assistant):
+        m.output_layer[1].p = 0.0
+    for p_ in teacher.parameters():
+        p_.requires_grad_(False)
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    lo = torch.randn(256, 3, 14, 14, device=DEV, generator=g)
+    hr = torch.nn.functional.interpolate(lo, size=(112, 112), mode="bilinear").clamp_(-1, 1).contiguous()
+    lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 7), size=(112, 112), mode="bilinear").contiguous()
+    try:
+        xrface.set_compute_dtype(torch.float32)
+        (sl32, al32), _ = c4_step(fhn, student, assistant, teacher, lr[:64], hr[:64])
+        for m in (*fhn.values(), student, assistant):
+            for p_ in m.parameters():
+                p_.grad = None
+        xrface.set_compute_dtype(torch.bfloat16)
+        (sl16, al16), _ = c4_step(fhn, student, assistant, teacher, lr[:64], hr[:64])
+        for m in (*fhn.values(), student, assistant):
+            for p_ in m.parameters():
+                p_.grad = None
+        print(f"[c4 N=64] student loss f32 {sl32.item():.5f} bf16 {sl16.item():.5f}; assistant f32 {al32.item():.5f} bf16 {al16.item():.5f}")
+        assert abs(sl16.item() - sl32.item()) < 3e-2 * abs(sl32.item())
+        assert abs(al16.item() - al32.item()) < 3e-2 * abs(al32.item())
+        fhn_params = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]
+        flats = [parallel.FlatParams(fhn_params), parallel.FlatParams(student.parameters()), parallel.FlatParams(assistant.parameters())]
+        (l1, a1), _ = c4_step(fhn, student, assistant, teacher, lr, hr)
+        torch.cuda.synchronize()
+        g1 = [f.grad.clone() for f in flats]
+        for f in flats:
+            f.zero_grad()
+        (l2, a2), _ = c4_step(fhn, student, assistant, teacher, lr, hr)
+        torch.cuda.synchronize()
+        assert l1.item() == l1.item() and a1.item() == a1.item()
+        assert abs(l2.item() - l1.item()) < 5e-3 * abs(l1.item()) and abs(a2.item() - a1.item()) < 5e-3 * abs(a1.item())
+        for f, ga in zip(flats, g1):
+            c = float(torch.nn.functional.cosine_similarity(f.grad, ga, dim=0))
+            assert c > 0.99, c
+        opts = [parallel.FusedRMSprop(flats[0], lr=1e-5), parallel.FusedSGD(flats[1], lr=0.05, momentum=0.9),
+                parallel.FusedSGD(flats[2], lr=0.05, momentum=0.9)]
+        hist = []
+        for _ in range(4):
+            (l_, _a), _ = c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts)
+            hist.append(l_.item())
+        print(f"[c4 N=256 bf16] student loss over 4 steps on a fixed batch: {hist}")
+        assert hist[-1] < hist[0]
+    finally:
+        xrface.set_compute_dtype(torch.float32)
+
+
+def test_fhn_step_fused_equals_literal_and_direct_mode():
+    """fhn_step_fused (one backward pass) == fhn_step (one partial traversal per (loss_k, theta_k) pair), and both stay
+    correct when the generators live in FlatParams(direct=True) buffers -- the literal form must then not let the traversal
+    of a foreign sub-network accumulate into that sub-network's flat gradient (ops.grad_only)."""
+    import xrface
+    from xrface import parallel
+    from xrface.model import FSRnet
+    from xrface.steps import fhn_step, fhn_step_fused
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("fsrnet_root.npz")
+    hr = G.synth_faces(2, 112, seed=1)
+    lr = G.synth_lr_from_hr(hr)
+    hm = G.synth_heatmap(2, 28, 97, 1.3, seed=2)
+    par = G.synth_parsing(2, 28, 11, seed=2)
+    args = (lr.to(DEV), hr.to(DEV), hm.to(DEV), par.to(DEV))
+    ctors = (("coarse", FSRnet.Course_SR_Network), ("encoder", FSRnet.Fine_SR_Encoder),
+             ("prior", FSRnet.Prior_Estimation_Network), ("decoder", FSRnet.Fine_SR_Decoder))
+
+    def check(nets, flat_mode, what):
+        for k in ("coarse", "encoder", "prior", "decoder"):
+            none_ref = set(st[f"fhn/{k}/none_grad_keys"].tolist())
+            named = dict(nets[k].named_parameters())
+            if flat_mode:
+                for n in none_ref:
+                    assert float(named[n].grad.abs().max()) == 0.0, (what, k, n)
+            else:
+                assert {n for n, p_ in named.items() if p_.grad is None} == none_ref, (what, k)
+            pre = f"fhn/{k}/grad/"
+            for key in st.files:
+                if key.startswith(pre):
+                    name = key[len(pre):].replace("@digest", "")
+                    check_against(st, pre + name, named[name].grad, GRAD_TOL, what=f"{what} {pre}{name}", floor=grad_floor(st, pre))
+
+    nets = {k: load_det(c())[0] for k, c in ctors}
+    losses, outs = fhn_step_fused(nets, *args)
+    check_against(st, "fhn/sr", outs["sr"], TOL)
+    for k in ("coarse", "encoder", "prior", "decoder"):
+        ref = float(st[f"fhn/loss/{k}"])
+        assert abs(losses[k].item() - ref) <= TOL * abs(ref), (k, losses[k].item(), ref)
+    check(nets, False, "fused")
+    for step_fn, what in ((fhn_step, "literal+flat"), (fhn_step_fused, "fused+flat")):
+        nets = {k: load_det(c())[0] for k, c in ctors}
+        flats = {k: parallel.FlatParams(nets[k].parameters()) for k in nets}
+        step_fn(nets, *args)
+        torch.cuda.synchronize()
+        check(nets, True, what)
+        for k, f in flats.items():   # .grad must still be the flat views
+            for p_, o in zip(f.params, f.offsets):
+                assert p_.grad is not None and p_.grad.data_ptr() == f.grad.data_ptr() + 4 * o
+
+
+def test_overall_network_gan_224_matches_reference_fixture():
+    """Row a7 / f4: OverallNetwork_GAN + Discriminator (model/FSRnet.py:461-545) run only at 224x224 (Linear(64*56*56, 512),
+    102.8 M parameters).  Train-mode forward (N = 3: BatchNorm batch statistics, bn_mid applied twice per call and the
+    discriminator called twice per forward -> four running-statistics updates), gradient of MSE(emb1, emb2) with respect to
+    the discriminator, eval-mode forward (N = 2)."""
+    import xrface
+    from xrface.loss.loss import MSELoss
+    from xrface.model.FSRnet import OverallNetwork_GAN
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("gan224.npz")
+    net, _ = load_det(OverallNetwork_GAN(), 7)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    hr = G.synth_faces(3, 224, seed=1, start=700)
+    lr = G.synth_lr_from_hr(hr)
+    net.train()
+    sr, coarse, lmk, par, e1, e2 = net(lr.to(DEV), hr.to(DEV))
+    assert sr.shape == (3, 3, 224, 224) and lmk.shape == (3, 97, 56, 56) and par.shape == (3, 11, 56, 56) and e1.shape == (3, 512)
+    for nm, t in (("sr", sr), ("coarse", coarse), ("landmark", lmk), ("parsing", par), ("emb1", e1), ("emb2", e2)):
+        check_against(st, "train/" + nm, t, TOL)
+    l_d = MSELoss()(e1, e2)
+    assert abs(l_d.item() - float(st["disc/loss"])) <= TOL * abs(float(st["disc/loss"]))
+    disc = net._discriminator
+    params = [p_ for p_ in disc.parameters()]
+    grads = torch.autograd.grad(l_d, params, allow_unused=True)
+    for (n, _), g_ in zip(disc.named_parameters(), grads):
+        disc.get_parameter(n).grad = g_
+    _check_prefixed_grads(st, "disc/", disc, KD_GRAD_TOL)
+    new_sd = net.state_dict()
+    for k in ("_discriminator.bn_mid.running_mean", "_discriminator.bn_mid.running_var", "_discriminator.bn_end.running_var"):
+        check_against(st, "train/stats/" + k, new_sd[k], TOL)
+    assert int(new_sd["_discriminator.bn_mid.num_batches_tracked"]) == int(st["train/nbt"]) == 4
+    net.load_state_dict(sd0)
+    net.eval()
+    with torch.no_grad():
+        outs = net(lr[:2].to(DEV), hr[:2].to(DEV))
+    for nm, t in zip(("sr", "coarse", "landmark", "parsing", "emb1", "emb2"), outs):
+        check_against(st, "eval/" + nm, t, TOL)

@@ -1,0 +1,120 @@
+"""GPU, world_size 2 over gloo on ONE card: the data-parallel layer around HIP-module models -- the exact path multi-GPU
+runs take (FlatParams with in-kernel gradient accumulation, weight gradients on the side stream, per-use-site signals into
+BucketedAllReduce(overlap=True), side-stream join before each bucket, fused optimizers), only with gloo instead of RCCL as
+the transport (a one-GPU box cannot host two RCCL ranks).  Replicas must stay bit-identical."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "cross-resolution-face-recognition_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import xrface
+        from xrface import ops, parallel
+        from xrface.loss.loss import CrossEntropyLoss, MSELossFunc
+        from xrface.model.FSRnet import Course_SR_Network
+        from xrface.model.model_irse import IR_SE_50
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(0)
+        xrface.set_compute_dtype(torch.float32)
+        assert ops._cfg["wgrad_stream"] == 1
+        res = {}
+        # ---- (1) shared-trunk generator: every trunk parameter accumulates at three sites per step
+        torch.manual_seed(100 + rank)                      # deliberately different initial weights per rank
+        net = Course_SR_Network().to(dev)
+        parallel.broadcast_module(net)
+        flat = parallel.FlatParams(net.parameters())
+        opt = parallel.FusedRMSprop(flat, lr=1e-3, alpha=0.99, weight_decay=1e-5)
+        red = parallel.BucketedAllReduce(flat, bucket_mb=0.1, overlap=True)
+        crit = MSELossFunc()
+        g = torch.Generator(device=dev).manual_seed(7 + rank)  # different data per rank
+        early = []
+        for step in range(4):
+            hr = torch.rand(2, 3, 112, 112, device=dev, generator=g) * 2 - 1
+            opt.zero_grad()
+            _, img = net(hr)
+            (12.0 * crit(img, hr)).backward()
+            early.append(list(red.launch_order))
+            red.finish()
+            opt.step()
+        torch.cuda.synchronize()
+        res["coarse"] = (flat.flat.cpu(), early, len(red.buckets))
+        # ---- (2) IR-SE-50: BatchNorm / SE / PReLU small-gradient paths, SE weight gradients on the side stream
+        torch.manual_seed(200 + rank)
+        net2 = IR_SE_50([112, 112]).to(dev).train()
+        net2.output_layer[1].p = 0.0
+        parallel.broadcast_module(net2)
+        flat2 = parallel.FlatParams(net2.parameters_in_execution_order())
+        opt2 = parallel.FusedSGD(flat2, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        red2 = parallel.BucketedAllReduce(flat2, bucket_mb=24.0, overlap=True)
+        ce = CrossEntropyLoss()
+        early2 = []
+        for step in range(3):
+            x = torch.rand(4, 3, 112, 112, device=dev, generator=g) * 2 - 1
+            y = torch.randint(0, 512, (4,), device=dev, generator=g)
+            opt2.zero_grad()
+            ce(net2(x), y).backward()
+            early2.append(list(red2.launch_order))
+            red2.finish()
+            opt2.step()
+        torch.cuda.synchronize()
+        stats = torch.cat([b.float().reshape(-1) for n, b in net2.named_buffers() if n.endswith("running_mean")])
+        res["irse"] = (flat2.flat.cpu(), early2, len(red2.buckets), stats.cpu())
+        q.put((rank, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_stay_bit_identical():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(2):
+            r, res = q.get(timeout=800)
+            got[r] = res
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
+    for tag in ("coarse", "irse"):
+        w0, early0, nb = got[0][tag][:3]
+        w1, early1, _ = got[1][tag][:3]
+        assert torch.equal(w0, w1), f"{tag}: replicas diverged after averaged-gradient steps"
+        assert torch.isfinite(w0).all()
+        assert early0[0] == [] and early1[0] == []          # step 1 learns the per-parameter signal counts
+        for e in early0[1:] + early1[1:]:
+            assert len(e) >= nb - 1, (tag, e, nb)           # (nearly) every bucket went out during backward
+            if tag == "irse":
+                # parameters were laid out in execution order, buckets are numbered from the last parameter backwards =
+                # the order backward finishes them: launches must be ascending
+                assert e == sorted(e), (tag, e)
+    # BatchNorm statistics are per GPU (the reference has no SyncBN): the ranks saw different data, so they must differ
+    assert not torch.equal(got[0]["irse"][3], got[1]["irse"][3])
