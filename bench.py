@@ -4,8 +4,11 @@
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-One step = IR-SE-50 forward + backward + gradient all-reduce (N > 1) + fused SGD update on a batch of
-synthetic 112x112 faces (BASELINE.json configs[1]: batch 256/GPU, bf16, train_teacher_model.py path).
+Headline (`value`): BASELINE.json configs[1] -- one step = IR-SE-50 forward + backward + gradient all-reduce (N > 1) + fused SGD
+update on a batch of 256 synthetic 112x112 faces per GPU, bf16 (train_teacher_model.py path).
+`secondary` (N = 1 only, timed after the headline with their own warm-up): the north-star composed step C4 (FHN -> IR-SE-50
+student + assistant vs frozen IR-SE-50 teacher, batch 256, BASELINE configs[3] per-GPU shape), C3 (full FHN step, batch 128),
+C1 (coarse net, batch 4, fp32) and C5 (1M-pair distances + ROC).
 Prints ONE JSON line from rank 0.
 """
 from __future__ import annotations
@@ -25,12 +28,14 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 IRSE50_FWD_GFLOP = 12.593          # algorithmic 2*MAC conv+linear FLOPs per 112x112 image
+FHN_FWD_GFLOP = 38.256             # root FHN: coarse 16.734 + encoder 1.113 + prior 3.230 + decoder 17.179
+C4_STEP_GFLOP = 203.0              # 3 x FHN + 3 x student + 3 x assistant + 1 x teacher
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA peak, MI355X (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 
 
 def synth_batch(n, dev, seed):
-    """Counter-free cheap synthetic faces on the device: smooth low-frequency field + noise in [-1,1]."""
+    """Cheap synthetic faces on the device: smooth low-frequency field + noise in [-1,1] (plumbing, outside the timed region)."""
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + seed)
     lo = torch.randn(n, 3, 14, 14, device=dev, generator=g)
@@ -40,62 +45,120 @@ def synth_batch(n, dev, seed):
     return x.contiguous(), y
 
 
-DOM_TAG = ("fwd", 256, 256, 14, 14, 3, 1)   # conv3x3 256->256 @14x14 stride 1 forward: 26 launches per IR-SE-50 step
+def synth_lr(hr):
+    """16x16 average-pooled and blown back up to 112x112 (the tensor contract of FHN_loader.py:65-66)."""
+    lo = torch.nn.functional.avg_pool2d(hr, 7)
+    return torch.nn.functional.interpolate(lo, size=(112, 112), mode="bicubic", align_corners=False).clamp_(-1, 1).contiguous()
 
 
-def dominant_kernel_roofline(dev, dtype, batch, probe_events, reps=10):
-    """Roofline of the dominant kernel (8-wave implicit-GEMM conv on MFMA, xr_conv8.hip igemm8_kernel<false,2,4,3>) at
-    its most frequent shape, conv3x3 256->256 @14x14 forward.  `achieved` uses the kernel's average duration INSIDE the
-    timed training steps (HIP event pairs recorded on the launch stream around each of its launches; ops._probe_begin);
-    the same kernel timed back-to-back in isolation is reported next to it."""
+# ------------------------------------------------------------------------------------------------- per-kernel roofline
+def _tag_name(tag):
+    kind, C, K, H, W, R, stride = tag
+    return f"{kind} conv{R}x{R} {C}->{K} @{H}x{W} s{stride}"
+
+
+def _out_hw(H, W, R, stride):
+    if R >= H:      # full-extent "convolution" = Linear on a flattened H x W map (padding 0)
+        return 1, 1
+    return (H + 2 * (R // 2) - R) // stride + 1, (W + 2 * (R // 2) - R) // stride + 1
+
+
+def _tag_flops(tag, batch):
+    kind, C, K, H, W, R, stride = tag
+    Ho, Wo = _out_hw(H, W, R, stride)
+    return 2.0 * batch * Ho * Wo * K * C * R * R
+
+
+def _kernel_of(tag, batch):
+    """Kernel template a launch site runs (the auto rule of csrc/xr_conv8.hip:igemm8_config restated; names as rocprofv3 shows them)."""
+    kind, C, K, H, W, R, stride = tag
+    if kind == "wgrad":
+        return "wgrad_kernel<0, %s, ...>" % ("128, 128" if K > 64 else "64, 256")
+    Ho, Wo = _out_hw(H, W, R, stride)
+    gk, gc, m = (K, C, batch * Ho * Wo) if kind == "fwd" else (C, K, batch * H * W)    # GEMM columns, reduction channels, rows
+    ok = gk % 8 == 0 and gc % 64 == 0 and R * R <= 32 and gc * R * R >= 512 and (kind == "fwd" or stride == 1)
+    if ok and gk % 256 == 0 and -(-m // 256) * (gk // 256) >= 160:
+        return "igemm8_kernel<%s, 8 waves, 256/224x256 tile>" % kind
+    if ok and gk % 128 == 0 and gk % 256 != 0 and -(-m // 512) * (gk // 128) >= 160:
+        return "igemm8_kernel<%s, 8 waves, 512/448x128 tile>" % kind
+    return "igemm_kernel<%s, 4 waves, 128x%d tile>" % (kind, 128 if gk > 64 else 64)
+
+
+def kernel_table(probe, batch, steps):
+    """Per conv launch site family (kind, shape): launches per step, average in-step duration (HIP event pairs on the launch
+    stream, one untimed probe step), TFLOP/s and fraction of the bf16 MFMA peak; sorted by total time."""
+    rows = []
+    for tag, evs in probe.items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        if not ms:
+            continue
+        avg = sum(ms) / len(ms)
+        fl = _tag_flops(tag, batch)
+        rows.append({"site": _tag_name(tag), "kernel": _kernel_of(tag, batch), "launches_per_step": len(ms) // max(steps, 1),
+                     "avg_ms": round(avg, 4), "total_ms_per_step": round(sum(ms) / max(steps, 1), 3),
+                     "tflops": round(fl / (avg * 1e-3) / 1e12, 1), "frac": round(fl / (avg * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                     "_tag": tag})
+    rows.sort(key=lambda r: -r["total_ms_per_step"])
+    return rows
+
+
+def isolated_ms(tag, batch, dev, reps=8):
+    """The same launch back-to-back in isolation (cache-warm operands, nothing else on the GPU)."""
     from xrface import ops
     from xrface._lib import dt, lib, ptr, stream
-    N, H, C, K = batch, 14, 256, 256
-    x = torch.randn(N, H, H, C, device=dev).to(dtype)
-    w = torch.randn(K, C, 3, 3, device=dev) * 0.02
-    pk, kg = ops._packed(w, "fwd", dtype, K, 1, 9, C, C, C * 9, 0, 1, 9)
-    y = torch.empty(N, H, H, K, device=dev, dtype=dtype)
-
-    def launch():
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), N, H, H, C, H, H, K, 3, 3, 1, 1, 0, kg, K, None, 0, None, None, None, 1, None, None, None, stream())
+    kind, C, K, H, W, R, stride = tag
+    pad = 0 if R >= H else R // 2
+    Ho, Wo = _out_hw(H, W, R, stride)
+    x = torch.randn(batch, H, W, C, device=dev).to(torch.bfloat16)
+    dy = torch.randn(batch, Ho, Wo, K, device=dev).to(torch.bfloat16)
+    w = torch.randn(K, C, R, R, device=dev) * 0.02
+    if kind == "fwd":
+        pk, kg = ops._packed(w, "fwd", torch.bfloat16, K, 1, R * R, C, C, C * R * R, 0, 1, R * R)
+        y = torch.empty_like(dy)
+        fn = lambda: lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, ptr(y), batch, H, W, C, Ho, Wo, K, R, R, stride, pad, 0, kg, K,
+                                       None, 0, None, None, None, 1, None, None, None, stream())
+    elif kind == "dgrad":
+        pk, kg = ops._packed(w, "dgrad", torch.bfloat16, C, 1, R * R, K, K, R * R, 0, 1, C * R * R)
+        dx = torch.empty_like(x)
+        fn = lambda: lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), batch, Ho, Wo, K, H, W, C, R, R, stride, pad, 1, kg, C,
+                                       None, 0, None, None, None, 1, None, None, None, stream())
+    else:
+        kg = ops.kg_of(R * R, C)
+        split = ops._wgrad_split(batch * Ho * Wo, K, kg)
+        slabs = torch.empty((split, K, kg), dtype=torch.float32, device=dev)
+        fn = lambda: lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), batch, H, W, C, Ho, Wo, K, R, R, stride, pad, 0, K, kg,
+                                       split, stream())
     for _ in range(3):
-        launch()
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        launch()
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    iso_ms = e0.elapsed_time(e1) / reps
-    if probe_events:
-        ms = sum(a.elapsed_time(b) for a, b in probe_events) / len(probe_events)
-    else:
-        ms = iso_ms
-    flops = 2.0 * N * H * H * K * C * 9
-    achieved = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per launch of this kernel at this shape come from the committed rocprofv3 PMC passes (FETCH_SIZE x2
-    # gfx950 correction + WRITE_SIZE; profiles/r01_dominant_kernel_pmc.json) -- bench.py cannot run the profiler itself
-    traffic = None
+    return e0.elapsed_time(e1) / reps
+
+
+def pmc_traffic(kernel, site):
+    """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC passes
+    (profiles/r02_counters.json, written by tools/pmc_kernels.sh at the current HEAD); None when that site was not profiled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_dominant_kernel_pmc.json")) as f:
-            pmc = json.load(f)
-        if batch == 256:
-            traffic = pmc["hbm_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as f:
+            db = json.load(f)
+        return db["sites"][site]["hbm_bytes_per_launch"]
     except Exception:
-        traffic = None
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "kernel": "igemm8_kernel<fwd, 224x256 tile, 8 waves> conv3x3 256->256 @14x14", "avg_launch_ms": round(ms, 4),
-            "launches_timed_in_step": len(probe_events), "isolated_launch_ms": round(iso_ms, 4),
-            "isolated_tflops": round(flops / (iso_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_launch": round(flops / 1e9, 2)}
+        return None
 
 
-def cpu_baseline(budget_s=12.0):
+# ------------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(dev, dtype, budget_s=12.0):
     """The CPU oracle (oracle/cpu_ref.py: stock torch fp32 CPU ops, the reference's module graph) timed on the
-    host cores on a bounded sample of the same workload: IR-SE-50 fwd+bwd at N = 8 per step."""
+    host cores on a bounded sample of the same workload: IR-SE-50 fwd+bwd at N = 8 per step.  The same leg checks the
+    embedding the timed mode (dtype) produces against the oracle's fp32 embedding on identical weights and inputs."""
     from oracle import cpu_ref as R
     from oracle import detgen as G
+    import xrface
     from xrface.model.model_irse import IR_SE_50
     try:
         cores = len(os.sched_getaffinity(0))
@@ -103,11 +166,20 @@ def cpu_baseline(budget_s=12.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))  # a 1-GPU box exposes 256 logical CPUs but grants a 16-CPU share
     torch.set_num_threads(cores)
-    tmpl = {k: v for k, v in IR_SE_50([112, 112]).state_dict().items()}
-    sd = G.det_state_dict(tmpl)
+    net = IR_SE_50([112, 112])
+    sd = G.det_state_dict(net.state_dict())
     n = 8
     x = G.synth_faces(n, 112, seed=1)
     t = G.synth_labels(n, 512)
+    # embedding parity of the benchmarked mode: eval-mode forward, HIP path (dtype) vs oracle (fp32 CPU)
+    net.load_state_dict(sd)
+    net.to(dev).eval()
+    xrface.set_compute_dtype(dtype)
+    with torch.no_grad():
+        e_gpu = net(x.to(dev)).float().cpu()
+        e_cpu, _ = R.ir_backbone(sd, x, se=True, train=False)
+    emb_err = float((e_gpu - e_cpu).norm(dim=1).max() / e_cpu.norm(dim=1).min())
+    del net
     R.teacher_step_grads(sd, x, t, se=True)  # warm-up
     steps, t0 = 0, time.perf_counter()
     while True:
@@ -117,7 +189,114 @@ def cpu_baseline(budget_s=12.0):
             break
     el = time.perf_counter() - t0
     return {"value": round(n * steps / el, 2), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"IR-SE-50 fwd+bwd (CE on the 512-d output), fp32, N={n}/step, {steps} steps in {el:.1f}s"}
+            "sample": f"IR-SE-50 fwd+bwd (CE on the 512-d output), fp32, N={n}/step, {steps} steps in {el:.1f}s"}, emb_err
+
+
+# ------------------------------------------------------------------------------------------------- secondary workloads
+def _timed(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, out
+
+
+def secondary_workloads(dev, c4_batch=256, c3_batch=128):
+    import numpy as np
+    import xrface
+    from xrface import parallel, steps
+    from xrface.loss.loss import MSELossFunc
+    from xrface.model import FSRnet, model_irse
+    from xrface.utils.utils import calculate_roc, pair_dist
+    out = []
+    xrface.set_compute_dtype(torch.bfloat16)
+    mk_fhn = lambda: {"coarse": FSRnet.Course_SR_Network().to(dev), "prior": FSRnet.Prior_Estimation_Network().to(dev),
+                      "encoder": FSRnet.Fine_SR_Encoder().to(dev), "decoder": FSRnet.Fine_SR_Decoder().to(dev)}
+    # ---- C4: the north-star composed step
+    torch.manual_seed(0)
+    fhn = mk_fhn()
+    student, assistant = model_irse.IR_SE_50([112, 112]).to(dev), model_irse.IR_SE_50([112, 112]).to(dev)
+    teacher = model_irse.IR_SE_50([112, 112]).to(dev).eval()
+    for p_ in teacher.parameters():
+        p_.requires_grad_(False)
+    fhn_params = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]
+    flats = [parallel.FlatParams(fhn_params), parallel.FlatParams(student.parameters_in_execution_order()),
+             parallel.FlatParams(assistant.parameters_in_execution_order())]
+    opts = [parallel.FusedRMSprop(flats[0], lr=1e-5, alpha=0.99, weight_decay=1e-5),
+            parallel.FusedRMSprop(flats[1], lr=1e-4, alpha=0.99, weight_decay=1e-5),
+            parallel.FusedRMSprop(flats[2], lr=1e-4, alpha=0.99, weight_decay=1e-5)]
+    hr, _ = synth_batch(c4_batch, dev, 11)
+    lr = synth_lr(hr)
+    ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts), 2, 4)
+    (sl, al), _ = res
+    tf = C4_STEP_GFLOP * c4_batch / ms            # GFLOP per ms = TFLOP/s
+    out.append({"workload": "C4 (BASELINE configs[3], per-GPU shape): root FHN (trainable) -> IR-SE-50 student + assistant vs frozen "
+                            "IR-SE-50 teacher on hr, residual-KD MSE losses, RMSprop x3, Dropout on, 112x112",
+                "per_gpu_batch": c4_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c4_batch / ms * 1e3, 1),
+                "algorithmic_tflop_per_step": round(C4_STEP_GFLOP * c4_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
+                "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "student_loss": round(float(sl), 5),
+                "assistant_loss": round(float(al), 5)})
+    del fhn, student, assistant, teacher, flats, opts, res
+    torch.cuda.empty_cache()
+    # ---- C3: full FHN step (per-network gradients from one backward pass), landmark + parsing losses
+    fhn = mk_fhn()
+    flats = {k: parallel.FlatParams(fhn[k].parameters()) for k in fhn}
+    opts = {k: parallel.FusedRMSprop(flats[k], lr=1e-5, alpha=0.99, weight_decay=1e-5) for k in fhn}
+    hr, _ = synth_batch(c3_batch, dev, 12)
+    lr = synth_lr(hr)
+    hm = torch.rand(c3_batch, 28, 28, device=dev)
+    par = torch.randint(0, 11, (c3_batch, 1, 28, 28), device=dev)
+    ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts), 2, 4)
+    tf = 3.0 * FHN_FWD_GFLOP * c3_batch / ms
+    out.append({"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
+                            "parsing losses, per-network gradients, RMSprop x4",
+                "per_gpu_batch": c3_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c3_batch / ms * 1e3, 1),
+                "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
+                "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
+    del fhn, flats, opts, res
+    torch.cuda.empty_cache()
+    # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case)
+    xrface.set_compute_dtype(torch.float32)
+    net = FSRnet.Course_SR_Network().to(dev)
+    opt = torch.optim.RMSprop(net.parameters(), lr=1e-4, alpha=0.99, weight_decay=1e-5)
+    hr4, _ = synth_batch(4, dev, 13)
+    lr4 = synth_lr(hr4)
+    crit = MSELossFunc()
+
+    def c1():
+        opt.zero_grad(set_to_none=True)
+        _, img = net(lr4)
+        (12.0 * crit(img, hr4)).backward()
+        opt.step()
+    ms, _ = _timed(c1, 3, 10)
+    out.append({"workload": "C1 (BASELINE configs[0]): Course_SR_Network fwd+bwd of 12*mse97 + RMSprop", "per_gpu_batch": 4,
+                "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 3), "images_per_s": round(4 / ms * 1e3, 1)})
+    del net, opt
+    xrface.set_compute_dtype(torch.bfloat16)
+    # ---- C5: P = 1e6 pair distances + 4000-threshold / 10-fold ROC
+    P = 1_000_000
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    e1 = torch.randn(P, 512, device=dev, generator=g)
+    same = torch.rand(P, device=dev, generator=g) < 0.5
+    e2 = torch.where(same[:, None], e1 + 0.5 * torch.randn(P, 512, device=dev, generator=g), torch.randn(P, 512, device=dev, generator=g))
+    ms, _ = _timed(lambda: pair_dist(e1, e2), 2, 8)
+    gbs = P * (2 * 512 * 4 + 4) / ms / 1e6
+    fold = np.random.RandomState(0).randint(0, 10, P).astype(np.int32)
+    same_h = same.cpu().numpy()
+    thr = np.arange(0, 12000, 3)
+    calculate_roc(thr, e1, e2, same_h, nrof_folds=10, fold_id=fold)
+    t0 = time.perf_counter()
+    _, _, acc, _ = calculate_roc(thr, e1, e2, same_h, nrof_folds=10, fold_id=fold)
+    torch.cuda.synchronize()
+    roc_ms = (time.perf_counter() - t0) * 1e3
+    out.append({"workload": "C5 (BASELINE configs[4]): 1M-pair 512-d squared-L2 distances + 4000-threshold / 10-fold ROC",
+                "pairs": P, "pairdist_ms": round(ms, 3), "pairdist_gb_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+                "calculate_roc_ms": round(roc_ms, 2), "accuracy": round(float(acc), 4)})
+    return out
 
 
 def main():
@@ -128,6 +307,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -185,6 +365,15 @@ def main():
     hp_ctx.__enter__()
     for i in range(args.warmup):
         step(i)
+    # one extra UNTIMED step with an event pair around every convolution launch (forward, input gradient, weight gradient;
+    # each on the stream it is launched on): the per-site table and the choice of the dominant kernel come from it
+    bf = dtype == torch.bfloat16
+    table = []
+    if rank == 0 and bf:
+        ops._cfg["probe"] = {"all": {}}
+        step(args.warmup)
+        torch.cuda.synchronize()
+        table = kernel_table(ops._cfg.pop("probe")["all"], args.batch, 1)
     if world > 1:
         dist.barrier()
         # replicas must still agree after the warm-up steps (same averaged gradients -> same weights)
@@ -192,9 +381,10 @@ def main():
         dist.broadcast(chk, 0)
         assert torch.equal(chk, flat.flat[:4096]), "replicas diverged: gradient all-reduce is broken"
     torch.cuda.synchronize()
-    probe = {"tag": DOM_TAG, "events": []}
-    if rank == 0 and args.batch == 256 and dtype == torch.bfloat16:
-        ops._cfg["probe"] = probe   # event pairs around the dominant kernel's launches (26 per step), timed region only
+    dom = table[0] if table else None
+    probe = {"tag": dom["_tag"] if dom else None, "events": []}
+    if dom is not None:
+        ops._cfg["probe"] = probe   # event pairs around the dominant site's launches only, inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
@@ -227,10 +417,28 @@ def main():
             "step_mfma": {"algorithmic_tflop_per_step": round(3.0 * IRSE50_FWD_GFLOP * gb / 1e3, 3),
                           "achieved_tflops": round(step_tflops, 1), "frac_of_bf16_peak_per_gpu":
                               round(step_tflops / world / PEAK_BF16_TFLOPS, 4)},
-            "roofline": dominant_kernel_roofline(dev, dtype, args.batch, probe["events"]),
         }
+        if dom is not None:
+            evs = probe["events"]
+            in_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs) if evs else dom["avg_ms"]
+            fl = _tag_flops(dom["_tag"], args.batch)
+            iso = isolated_ms(dom["_tag"], args.batch, dev)
+            line["roofline"] = {
+                "bound": "mfma", "achieved": round(fl / (in_ms * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl / (in_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"], dom["site"]),
+                "kernel": dom["kernel"], "site": dom["site"], "selection": "largest total in-step time among all conv launch sites",
+                "avg_launch_ms": round(in_ms, 4), "launches_timed_in_step": len(evs), "launches_per_step": dom["launches_per_step"],
+                "isolated_launch_ms": round(iso, 4), "isolated_tflops": round(fl / (iso * 1e-3) / 1e12, 1),
+                "algorithmic_gflop_per_launch": round(fl / 1e9, 2)}
+            line["kernels"] = [{k: v for k, v in r.items() if k != "_tag"} for r in table[:8]]
+            line["conv_ms_per_step_probed"] = round(sum(r["total_ms_per_step"] for r in table), 2)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            line["cpu_baseline"], emb_err = cpu_baseline(dev, dtype)
+            line["embedding_rel_l2_vs_cpu"] = round(emb_err, 6)
+        if world == 1 and not args.no_secondary and bf:
+            del model, flat, opt, reducer
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_workloads(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -44,6 +44,9 @@ class GraphedStep:
         with torch.cuda.stream(side):   # warm-up: lazy initialisation, weight-pack tables, allocator pools
             for _ in range(warmup):
                 fn(*self.static_in)
+            # the set of stale weight packs the captured step will meet (this step's own parameters; other models' pending
+            # refreshes were flushed by the warm-up) gets its descriptor table now -- a capture cannot build one
+            ops._pack_plan.prebuild()
         cur.wait_stream(side)
         torch.cuda.synchronize(dev)
         if ops._graph["tick"] is None or ops._graph["tick"].device != dev:
@@ -58,18 +61,28 @@ class GraphedStep:
             with torch.cuda.graph(graph):
                 self.tick.add_(1)
                 self.static_out = fn(*self.static_in)
+        except BaseException:
+            # a step that raises inside the capture leaves torch's context manager half unwound (its capture_end() raises as
+            # well, before the previous stream is restored): put the caller's stream back so that later work does not run on
+            # the abandoned capture stream
+            try:
+                torch.cuda.set_stream(cur)
+            except Exception:
+                pass
+            self.static_out = None
+            raise
         finally:
             ops._graph["capturing"] = False
             ops._zpool.buf = None   # the slab captured above belongs to the graph's memory pool
         self.graph = graph
 
     def __call__(self, *inputs):
+        if self.graph is None:
+            raise RuntimeError("GraphedStep: called after close()")
         assert len(inputs) == len(self.static_in)
         for s, t in zip(self.static_in, inputs):
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t, non_blocking=True)
-        if self.graph is None:
-            raise RuntimeError("GraphedStep: called after close()")
         self.graph.replay()
         ops.invalidate_weight_cache()   # the replay moved parameters / running statistics without bumping any version
         return self.static_out

@@ -183,15 +183,21 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
         side = _side_fork(dev)     # side stream now waits for everything enqueued on the current stream (x, dy, zeroed grads)
         sh = side.cuda_stream      # launch on the side stream by handle: no current-stream switch on the host
         slabs = torch.empty((split, K, kg), dtype=torch.float32, device=dev)
+        pe = _probe_begin(("wgrad", Cp, K, H, W, R, stride), side)
         ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
                                kg, split, sh)
+        if pe is not None:
+            pe.record(side)
         lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, sh)
         _side_done(side, (x, dy, slabs))
         _direct_done(w)
         return None
     slabs = torch.empty((split, K, kg), dtype=torch.float32, device=x.device)
+    pe = _probe_begin(("wgrad", Cp, K, H, W, R, stride))
     ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg,
                            split, stream())
+    if pe is not None:
+        pe.record()
     if tgt is not None:
         lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, stream())
         _direct_done(w)
@@ -212,15 +218,23 @@ def _emit_small(p, val):
 
 
 # ------------------------------------------------------------------------------------------------- launch probe
-def _probe_begin(tag):
-    """bench.py times the dominant kernel INSIDE the training step: when _cfg["probe"] names this launch's shape tag, a HIP
-    event pair on the launch stream brackets it.  No-op (one dict lookup) otherwise."""
+def _probe_begin(tag, on=None):
+    """bench.py times convolution launches INSIDE the training step with HIP event pairs recorded on the stream the kernel is
+    launched on (`on`: a torch.cuda.Stream, default the current one).  _cfg["probe"] = {"tag": t, "events": []} brackets the
+    launches of ONE site family (kind, C, K, H, W, R, stride); {"all": {}} brackets every family (an untimed survey step).
+    No-op (one dict lookup) otherwise.  Returns the end event (the caller records it after the launch) or None."""
     pr = _cfg.get("probe")
-    if pr is None or pr["tag"] != tag:
+    if pr is None:
+        return None
+    every = pr.get("all")
+    if every is None and pr.get("tag") != tag:
         return None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    pr["events"].append((e0, e1))
+    if on is None:
+        e0.record()
+    else:
+        e0.record(on)
+    (every.setdefault(tag, []) if every is not None else pr["events"]).append((e0, e1))
     return e1
 
 
@@ -253,6 +267,7 @@ class _PackPlan:
         self.entries = []     # [weakref(w), key, pk, kg, args]
         self.index = {}       # (id(w), key) -> entry
         self.tables = {}      # tuple(entry ids) -> (table, (n, blocks, smem), [src ptrs])
+        self.builds = 0       # descriptor tables built so far (GraphedStep warms up until a step builds none)
 
     def add(self, w, key, pk, kg, args):
         e = [weakref.ref(w), key, pk, kg, args]
@@ -269,6 +284,26 @@ class _PackPlan:
         smem = ctypes.c_int(0)
         blocks = lib.xr_pack_plan(ent.ctypes.data, len(sel), ptr(table), ctypes.addressof(smem), stream())
         return table, (len(sel), blocks, smem.value), [w.data_ptr() for w, _ in sel]
+
+    def prebuild(self):
+        """Build (without running) the descriptor table of the CURRENTLY stale set.  GraphedStep calls this right before it
+        captures: the first convolution of the captured step then finds its table cached -- building one uploads from the
+        host and waits, which a capture cannot contain."""
+        stale = []
+        for e in self.entries:
+            w = e[0]()
+            hit = None if w is None else w.__dict__.get("_xr_pack", {}).get(e[1])
+            if hit is not None and hit[1] is e[2] and hit[0] != _pack_tag(w) and w.dtype == torch.float32 and w.is_contiguous():
+                stale.append((w, e))
+        if not stale:
+            return
+        key = tuple(id(e) for _, e in stale)
+        ent = self.tables.get(key)
+        if ent is None or ent[2] != [w.data_ptr() for w, _ in stale] or ent[0].device != stale[0][0].device:
+            if len(self.tables) >= 8:
+                self.tables.clear()
+            self.tables[key] = self._build(stale)
+            self.builds += 1
 
     def refresh(self):
         stale, dead = [], False
@@ -289,9 +324,18 @@ class _PackPlan:
         key = tuple(id(e) for _, e in stale)
         ent = self.tables.get(key)
         if ent is None or ent[2] != [w.data_ptr() for w, _ in stale] or ent[0].device != stale[0][0].device:
+            if _graph["capturing"]:
+                # a stale set never seen before shows up inside a HIP-graph capture: building its descriptor table uploads
+                # from the host and waits (not capturable) -- refresh these packs one launch each instead
+                for w, e in stale:
+                    planes, A1, A2, taps, B, Bp, sa1, sa2, st, sb = e[4]
+                    lib.xr_pack_weight(ptr(w.detach()), ptr(e[2]), planes, A1, A2, taps, B, Bp, e[3], sa1, sa2, st, sb, stream())
+                    w.__dict__["_xr_pack"][e[1]] = (_pack_tag(w), e[2], e[3])
+                return
             if len(self.tables) >= 8:
                 self.tables.clear()
             ent = self.tables[key] = self._build(stale)
+            self.builds += 1
         n, blocks, smem = ent[1]
         lib.xr_pack_run(ptr(ent[0]), n, blocks, smem, stream())
         for w, e in stale:
@@ -497,9 +541,12 @@ class _Conv2d(Function):
                 if dpass.dtype != x.dtype:
                     dpass = dpass.to(x.dtype)
             add_in_kernel = dpass is not None and red is None and C % 8 == 0
+            pe = _probe_begin(("dgrad", Cp, K, H, W, R, stride))
             lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
                               kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red),
                               ptr(dpass) if add_in_kernel else None, stream())
+            if pe is not None:
+                pe.record()
             if dpass is not None and not add_in_kernel:
                 dx = dx + dpass
             if red is not None:
@@ -674,8 +721,11 @@ class _PreluConv2d(Function):
                 dal_s = dal = t_a if t_a is not None else zeros_f32((C,), dev)
             pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
+            pe = _probe_begin(("dgrad", Cp, K, H, W, R, stride))
             lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
                               0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, None, stream())
+            if pe is not None:
+                pe.record()
             if sp > 1:
                 lib.xr_reduce_groups(ptr(dal_s), ptr(dal), 1, sp, C, 1 if t_a is not None else 0, stream())
             if t_a is not None:

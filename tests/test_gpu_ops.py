@@ -434,6 +434,39 @@ def test_cross_entropy_rows():
     assert rel(xg.grad, xr.grad) < 1e-4
 
 
+def test_fused_optimizer_mask_semantics():
+    """wd_mask bit 0 = weight decay on, bit 1 = skip the element (a parameter without gradient is left alone, as a stock
+    optimizer skips .grad None -- including its weight decay)."""
+    from xrface._lib import lib, ptr, stream
+    m = 3000
+    p0, g = rnd("mkp", m).to(DEV), rnd("mkg", m).to(DEV)
+    mask = torch.ones(m, dtype=torch.uint8, device=DEV)
+    mask[1000:2000] = 0
+    mask[2000:] = 2
+    g[2000:] = 0
+    for kind in ("sgd", "rmsprop", "adam"):
+        pa, pb = p0.clone(), p0.clone()
+        sa, sb, va, vb = (torch.zeros(m, device=DEV) for _ in range(4))
+        if kind == "sgd":
+            lib.xr_sgd_step(ptr(pa), ptr(g), ptr(sa), m, 0.1, 0.9, 1e-2, ptr(mask), 1, stream())
+            lib.xr_sgd_step(ptr(pb), ptr(g), ptr(sb), m, 0.1, 0.9, 1e-2, None, 1, stream())
+            lib.xr_sgd_step(ptr(vb.copy_(p0)), ptr(g), ptr(va), m, 0.1, 0.9, 0.0, None, 1, stream())
+        elif kind == "rmsprop":
+            lib.xr_rmsprop_step(ptr(pa), ptr(g), ptr(sa), m, 5e-3, 0.99, 1e-8, 1e-2, ptr(mask), stream())
+            lib.xr_rmsprop_step(ptr(pb), ptr(g), ptr(sb), m, 5e-3, 0.99, 1e-8, 1e-2, None, stream())
+            lib.xr_rmsprop_step(ptr(vb.copy_(p0)), ptr(g), ptr(va), m, 5e-3, 0.99, 1e-8, 0.0, None, stream())
+        else:
+            s2a, s2b, s2c = (torch.zeros(m, device=DEV) for _ in range(3))
+            lib.xr_adam_step(ptr(pa), ptr(g), ptr(sa), ptr(s2a), m, 1e-3, 0.5, 0.999, 1e-8, 1e-2, 1, None, 0, ptr(mask), stream())
+            lib.xr_adam_step(ptr(pb), ptr(g), ptr(sb), ptr(s2b), m, 1e-3, 0.5, 0.999, 1e-8, 1e-2, 1, None, 0, None, stream())
+            lib.xr_adam_step(ptr(vb.copy_(p0)), ptr(g), ptr(va), ptr(s2c), m, 1e-3, 0.5, 0.999, 1e-8, 0.0, 1, None, 0, None, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(pa[:1000], pb[:1000]), kind                 # decay on: same as no mask
+        assert torch.equal(pa[1000:2000], vb[1000:2000]), kind         # decay off: same as weight_decay = 0
+        assert torch.equal(pa[2000:], p0[2000:]), kind                 # skipped: untouched ...
+        assert not torch.equal(pb[2000:], p0[2000:]), kind             # ... while the unmasked update decays it
+
+
 def test_fused_optimizers_match_torch_optim():
     from xrface._lib import lib, ptr, stream
     n = 10007
@@ -455,9 +488,9 @@ def test_fused_optimizers_match_torch_optim():
             if kind == "sgd":
                 lib.xr_sgd_step(ptr(pg), ptr(gg), ptr(s1), n, 0.1, 0.9, 1e-3, None, int(step == 1), stream())
             elif kind == "rmsprop":
-                lib.xr_rmsprop_step(ptr(pg), ptr(gg), ptr(s1), n, 5e-3, 0.99, 1e-8, 1e-5, stream())
+                lib.xr_rmsprop_step(ptr(pg), ptr(gg), ptr(s1), n, 5e-3, 0.99, 1e-8, 1e-5, None, stream())
             else:
-                lib.xr_adam_step(ptr(pg), ptr(gg), ptr(s1), ptr(s2), n, 1e-3, 0.5, 0.999, 1e-8, 1e-5, step, None, 0, stream())
+                lib.xr_adam_step(ptr(pg), ptr(gg), ptr(s1), ptr(s2), n, 1e-3, 0.5, 0.999, 1e-8, 1e-5, step, None, 0, None, stream())
         assert rel(pg, pr) < 2e-6, kind
 
 
