@@ -104,6 +104,20 @@ int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, v
  * and each group only visits the taps it can see (no multiply-by-zero work). */
 int xr_bias_cast(int dtype, const float* ws, const float* bias, void* out, int64_t M, int K, int ld, void* stream);
 
+/* Weights-stationary direct convolution for the 64 -> 64 channel 3x3 / stride 1 / pad 1 bf16 layers (model/FSRnet.py:79,85: every
+ * FSRNet body layer; model_irse.py:59 and model/resnet.py:9-12 stage 1).  Same result as xr_conv_igemm(XR_BF16, ..., C = K = 64,
+ * R = S = 3, stride 1, pad 1, transposed) on the same weight pack (wpack = [64][576] bf16, one plane; for transposed != 0 the
+ * input-gradient pack), with these fusions:
+ *   in_scale / in_shift [N][64] (+ in_alpha [64], optional): the input is transformed ON LOAD, per image n and channel c,
+ *     x' = prelu(x * in_scale[n][c] + in_shift[n][c], in_alpha[c]) -- the InstanceNorm apply + PReLU of the producing layer
+ *     (model/FSRnet.py:81-84,92-94), zero padding applies to x'; the normalised activation is never written to HBM;
+ *   out_stats [2][N][64] (zeroed by the caller): += per-image sum and sum of squares of the output as rounded to bf16 -- the
+ *     statistics of the InstanceNorm that follows (xr_norm_finalize(G = N));
+ *   ep_add (laid out like out): out += ep_add (residual-branch gradient, as xr_conv_igemm's ep_add); exclusive with out_stats. */
+int xr_conv64_direct(const void* in, const void* wpack, const float* bias, void* out, int N, int H, int W, int transposed,
+                     const float* in_scale, const float* in_shift, const float* in_alpha, float* out_stats, const void* ep_add,
+                     void* stream);
+
 /* Weight gradient (aten::convolution_backward weight part; same call sites as above).
  * slab[s][k][t*C + c] = sum_{m in slice s} dy[m][k] * gather(in)[m][t][c]   (fp32, PACKED layout [K][Kg])
  * where m runs over the N*Ho*Wo pixels of dy (row pitch ldy), split into `split` contiguous slices, and gather()

@@ -1,0 +1,127 @@
+"""GPU: the weights-stationary direct 64->64 3x3 convolution (csrc/xr_conv64.hip) against the fp32 CPU convolution and
+against the implicit-GEMM kernel it replaces, including its fusions (normalise + PReLU on load, per-image output
+statistics, residual-gradient sum, bias) and ragged images (edge tiles)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import detgen as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def rnd(key, *shape, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((G.normal(key, n) * scale).reshape(shape).astype(np.float32))
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+
+
+CASES = [  # N, H, W
+    (2, 32, 32),     # 2 x 2 full tiles per image
+    (3, 20, 28),     # ragged: edge tiles in both directions
+    (1, 112, 112),   # the FSRNet layer
+    (5, 7, 9),       # image smaller than one tile
+    (300, 16, 16),   # more tiles than workgroups hold in one pass is not needed: 300 tiles over <= 256 workgroups
+]
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("case", CASES)
+def test_direct_conv64_forward_and_input_gradient(case, wide):
+    from xrface import ops
+    from xrface._lib import lib, ptr, stream
+    N, H, W = case
+    lib.xr_tune(13, wide)
+    try:
+        x = rnd(f"d64x{case}", N, 64, H, W).bfloat16().float()
+        w = rnd(f"d64w{case}", 64, 64, 3, 3, scale=(64 * 9) ** -0.5)
+        b = rnd(f"d64b{case}", 64, scale=0.1)
+        gy = rnd(f"d64g{case}", N, 64, H, W).bfloat16().float()
+        y_ref = F.conv2d(x, w, b, 1, 1)
+        dx_ref = F.conv_transpose2d(gy, w, None, 1, 1)          # input gradient of the (bias-free) convolution
+        xb = _nhwc(x).to(DEV).bfloat16()
+        gb = _nhwc(gy).to(DEV).bfloat16()
+        wd = w.to(DEV)
+        pk, _ = ops._packed(wd, "fwd", torch.bfloat16, 64, 1, 9, 64, 64, 64 * 9, 0, 1, 9)
+        pkd, _ = ops._packed(wd, "dgrad", torch.bfloat16, 64, 1, 9, 64, 64, 9, 0, 1, 64 * 9)
+        y = torch.empty_like(xb)
+        dx = torch.empty_like(xb)
+        bias = b.to(DEV)
+        lib.xr_conv64_direct(ptr(xb), ptr(pk), ptr(bias), ptr(y), N, H, W, 0, None, None, None, None, None, stream())
+        lib.xr_conv64_direct(ptr(gb), ptr(pkd), None, ptr(dx), N, H, W, 1, None, None, None, None, None, stream())
+        torch.cuda.synchronize()
+        assert rel(y.float().permute(0, 3, 1, 2), y_ref) < 1e-2
+        assert rel(dx.float().permute(0, 3, 1, 2), dx_ref) < 1e-2
+        # against the implicit-GEMM kernel on the same packs: same products, fp32 accumulation in another order, one bf16 rounding
+        y2 = torch.empty_like(xb)
+        dx2 = torch.empty_like(xb)
+        lib.xr_conv_igemm(0, ptr(xb), ptr(pk), ptr(bias), ptr(y2), N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 576, 64, None, 0, None, None, None,
+                          1, None, None, None, stream())
+        lib.xr_conv_igemm(0, ptr(gb), ptr(pkd), None, ptr(dx2), N, H, W, 64, H, W, 64, 3, 3, 1, 1, 1, 576, 64, None, 0, None, None, None,
+                          1, None, None, None, stream())
+        torch.cuda.synchronize()
+        assert rel(y.float(), y2.float()) < 8e-3 and rel(dx.float(), dx2.float()) < 8e-3
+        assert float((y.float() - y2.float()).abs().mean()) < 2e-3 * float(y2.float().abs().mean())
+    finally:
+        lib.xr_tune(13, 0)
+
+
+@pytest.mark.parametrize("transposed", [0, 1])
+@pytest.mark.parametrize("case", [(2, 32, 32), (3, 20, 28), (2, 112, 112)])
+def test_direct_conv64_fusions(case, transposed):
+    """Normalise + PReLU on load (zero padding applies AFTER the transform), per-image output statistics, ep_add."""
+    from xrface import ops
+    from xrface._lib import lib, ptr, stream
+    N, H, W = case
+    x = (rnd(f"f64x{case}", N, 64, H, W) * 1.5 + 0.4).bfloat16().float()
+    w = rnd(f"f64w{case}", 64, 64, 3, 3, scale=(64 * 9) ** -0.5)
+    sc = rnd(f"f64s{case}", N, 64) * 0.3 + 1.0
+    sh = rnd(f"f64h{case}", N, 64) * 0.5
+    al = rnd(f"f64a{case}", 64).abs() * 0.3 + 0.05
+    add = rnd(f"f64e{case}", N, 64, H, W).bfloat16().float()
+    z = x * sc[:, :, None, None] + sh[:, :, None, None]
+    xn = torch.where(z > 0, z, z * al[None, :, None, None]).bfloat16().float()     # what the kernel feeds the MFMAs
+    if transposed:
+        y_ref = F.conv_transpose2d(xn, w, None, 1, 1)
+    else:
+        y_ref = F.conv2d(xn, w, None, 1, 1)
+    xb = _nhwc(x).to(DEV).bfloat16()
+    wd = w.to(DEV)
+    if transposed:
+        pk, _ = ops._packed(wd, "dgrad", torch.bfloat16, 64, 1, 9, 64, 64, 9, 0, 1, 64 * 9)
+    else:
+        pk, _ = ops._packed(wd, "fwd", torch.bfloat16, 64, 1, 9, 64, 64, 64 * 9, 0, 1, 9)
+    scd, shd, ald = sc.to(DEV), sh.to(DEV), al.to(DEV)
+    # (a) transform on load + output statistics
+    y = torch.empty_like(xb)
+    stats = torch.zeros(2, N, 64, device=DEV)
+    lib.xr_conv64_direct(ptr(xb), ptr(pk), None, ptr(y), N, H, W, transposed, ptr(scd), ptr(shd), ptr(ald), ptr(stats), None, stream())
+    torch.cuda.synchronize()
+    yf = y.float()
+    assert rel(yf.permute(0, 3, 1, 2), y_ref) < 1e-2
+    s_ref = torch.stack((yf.sum((1, 2)), (yf * yf).sum((1, 2))))      # statistics are taken of the ROUNDED output
+    assert rel(stats, s_ref) < 2e-5
+    # (b) affine only (no activation), and ep_add
+    z2 = z.bfloat16().float()
+    y_ref2 = (F.conv_transpose2d(z2, w, None, 1, 1) if transposed else F.conv2d(z2, w, None, 1, 1)) + add
+    y2 = torch.empty_like(xb)
+    addb = _nhwc(add).to(DEV).bfloat16()
+    lib.xr_conv64_direct(ptr(xb), ptr(pk), None, ptr(y2), N, H, W, transposed, ptr(scd), ptr(shd), None, None, ptr(addb), stream())
+    torch.cuda.synchronize()
+    assert rel(y2.float().permute(0, 3, 1, 2), y_ref2) < 1e-2
+
+
+def test_direct_conv64_argument_checks():
+    from xrface._lib import lib
+    with pytest.raises(RuntimeError, match="xr_conv64_direct"):
+        lib.xr_conv64_direct(None, None, None, None, 1, 16, 16, 0, None, None, None, None, None, None)
