@@ -4,22 +4,30 @@
 //
 // Why not the implicit GEMM of xr_conv.hip: with C = K = 64 a K-loop has only nine stages, the im2col gather re-reads the
 // input nine times through the texture path and the 128x64 tiles are instruction-issue bound (~13 VALU per MFMA).  Here
-//   * the 64 x 576 weight panel lives in REGISTERS as MFMA A-operand fragments for the whole kernel (persistent workgroups);
+//   * the 64 x 576 weight panel lives in REGISTERS as MFMA A-operand fragments for the whole kernel: persistent workgroups
+//     (one per CU, 8 waves = two per SIMD), wave = (32-channel half, 2 of the 8 pixel blocks) -> 144 weight VGPRs, 32
+//     accumulator registers, everything within the 256 registers a wave may have at two waves per SIMD;
 //   * a workgroup walks a contiguous run of 16x16-pixel output tiles; the 18x18-pixel input tile with halo is staged ONCE
-//     into LDS (global -> registers -> LDS, double buffered: the loads of tile t+1 are in flight under the MFMAs of tile t)
-//     and all nine taps are read from LDS with ds_read_b128;
+//     into LDS (global -> registers -> LDS, double buffered) and all nine taps are read from LDS with ds_read_b128;
 //   * staging goes through registers because it can TRANSFORM: y = prelu(x * scale[n][c] + shift[n][c], alpha[c]) -- the
 //     InstanceNorm apply + PReLU of the producing layer (model/FSRnet.py:81-84) is folded into the consumer's load, once
 //     per input element (an im2col gather would pay it nine times), so the normalised activation never exists in HBM;
 //   * MFMA is v_mfma_f32_32x32x16_bf16 with the 32 "rows" = 2 image rows x 16 columns: the LDS image is pixel-major
 //     (128 B per pixel) with the 16-B chunk XOR-swizzled by (halo column >> 1) & 7 -- conflict-free ds_read_b128 for every
 //     tap shift (the 16-lane groups of a b128 read then see each 16-B slot of the 256-B bank row once);
+//   * the kernel is a hand-laid software pipeline: the 72 MFMAs a wave issues per tile are the clock; every MFMA is followed
+//     by a slot of "side work" that issues under it (an MFMA holds the vector issue port for 8 of its 32 cycles): the
+//     fragment read of the next stage, the global loads of tile t+1, the stream-out of tile t-1's output image (LDS -> HBM,
+//     + statistics / residual sum) and the transform + LDS write of tile t+1.  The sibling wave of the SIMD fills the stalls
+//     (a first version with one 512-register wave per SIMD ran at 3.5 us per tile with every load / store latency exposed
+//     on top).  Only the accumulator -> LDS epilogue and two barriers per tile are not overlapped;
 //   * accumulators are kept transposed (D[channel][pixel]): a lane owns 4 consecutive channels of a pixel, the epilogue
-//     writes 8-byte packets into an LDS image and streams full 128-B pixel rows out;
+//     writes 8-byte packets into an LDS image from which full 128-B pixel rows are streamed out;
 //   * epilogue fusions: bias; per-image sum / sum of squares of the (rounded) output for the InstanceNorm that follows
 //     (accumulated in registers across the tiles of one image, one atomic per channel and image change); residual-gradient
 //     sum (out += ep_add).
 #include "xr_common.h"
+#include <type_traits>
 
 extern int g_tune[16];
 
@@ -29,38 +37,58 @@ constexpr int NT = 256;
 constexpr int TS = 16;                    // output tile edge
 constexpr int HS = TS + 2;                // halo tile edge
 constexpr int HPIX = HS * HS;             // 324 halo pixels
-constexpr int INBUF = HPIX * 128;         // one input stage (bytes)
-constexpr int NCH = (HPIX * 8 + NT - 1) / NT;  // 16-B chunks a thread stages per tile (11)
-constexpr int OPITCH = 144;               // epilogue image pitch (bytes): 16-B aligned, rows 4 banks apart
-static_assert(TS * TS * OPITCH <= INBUF, "the output image reuses an input stage");
+constexpr int INBUF = (HPIX + 1) * 128;   // one input stage (bytes); row 324 is a dump slot for the lanes of the ragged last chunk
+constexpr int NCH = (HPIX * 8 + NT - 1) / NT;  // 16-B chunks a thread stages per tile (11 at 256 threads)
+constexpr int RPP = NT / 8;               // pixel rows one pass of the workgroup covers (64)
+constexpr int NOUT = TS * TS / RPP;       // output-image row groups per thread (4)
+constexpr int OPITCH = 144;               // output image pitch (bytes): 16-B aligned, rows 4 banks apart
+constexpr int OUTIMG = TS * TS * OPITCH;  // 36,864 B
+constexpr int OUTBASE = 2 * INBUF;
+constexpr int SMEM = 2 * INBUF + OUTIMG;  // 120,064 B
 
 typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
 #define XR64_OOR 0x80000000u
+
+// compile-time loop: f(std::integral_constant<int, i>) for i in [B, E) -- the pipeline below indexes register arrays with the
+// loop counter, which must therefore never become a run-time value (a failed "#pragma unroll" would send them to scratch)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
 
 struct DC64P {
   const bf16_t* in;
   const bf16_t* w;        // [64][576] bf16: row = GEMM output channel, column = tap * 64 + reduction channel
   const float* bias;      // [64] or null
   bf16_t* out;
-  const bf16_t* ep_add;   // laid out like out, or null
-  const float* n_scale;   // [N][64] per-image affine applied to the input on load, or null
+  const bf16_t* ep_add;   // laid out like out (EP == 2)
+  const float* n_scale;   // [N][64] per-image affine applied to the input on load (NORM)
   const float* n_shift;
   const float* n_alpha;   // [64] PReLU slope applied after the affine, or null (no activation)
-  float* stats;           // [2][N][64]: sum, sum of squares of the output per image and channel, or null
+  float* stats;           // [2][N][64]: sum, sum of squares of the output per image and channel (EP == 1)
   int N, H, W, tiles_x, tiles_img, ntiles, tpw;
-  unsigned in_bytes;
-  int dbg;   // tuning knob 14 (bit 0: skip staging after the first tile, bit 1: skip the accumulator -> LDS epilogue, bit 2: skip the
-             // store phase, bit 3: skip the MFMA stages) -- timing experiments only, results are wrong
+  unsigned io_bytes;      // extent of in / out / ep_add (same shape)
+  int dbg;                // tuning knob 14, timing experiments only (results are wrong): bit 0 no halo loads, bit 1 no
+                          // accumulator -> LDS epilogue, bit 2 no output stores
 };
 
-// CBW = 32-channel blocks per wave: 2 -> a wave owns 2 pixel blocks x all 64 channels (288 weight VGPRs, 72 fragment reads
-// per tile), 1 -> 4 pixel blocks x 32 channels (144 weight VGPRs, 144 fragment reads per tile)
-template <bool TR, bool NORM, int CBW>
+struct TileGeo {          // wave-uniform description of one tile
+  int n, y0, x0;
+  int base;               // byte offset of pixel (y0, x0) of image n
+  bool interior;          // the whole halo lies inside the image
+};
+
+// EP: 0 plain, 1 per-image output statistics, 2 out += ep_add
+template <bool TR, bool NORM, int EP>
 __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
-  constexpr int WN = 2 / CBW, WM = 4 / WN, NPB = 8 / WM;
+  constexpr int NPB = 4;   // pixel blocks (32 pixels = 2 image rows x 16 columns) per wave
+  constexpr int NSLOT = 36 * NPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wm = wave >> 1, wn = wave & 1;     // pixel-block half, 32-channel half
   const int lp = lane & 31, kg = lane >> 5;
 
   int tile = blockIdx.x * p.tpw;
@@ -68,98 +96,144 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   if (tile_end > p.ntiles) tile_end = p.ntiles;
   if (tile >= tile_end) return;
 
-  // ---- weight panel -> registers (MFMA A operand: row = channel lp of the block, 8 reduction elements 8*kg..+7 of the step)
-  bf16x8_t wf[9][4][CBW];
+  // ---- weight panel -> registers (MFMA A operand: row = channel lp of the half, 8 reduction elements 8*kg..+7 of the step)
+  bf16x8_t wf[9][4];
 #pragma unroll
   for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int j = 0; j < CBW; ++j) {
-        const int row = (wn * CBW + j) * 32 + lp;
-        wf[tp][ks][j] = *reinterpret_cast<const bf16x8_t*>(p.w + (size_t)row * 576 + tp * 64 + ks * 16 + kg * 8);
-      }
+      wf[tp][ks] = *reinterpret_cast<const bf16x8_t*>(p.w + (size_t)(wn * 32 + lp) * 576 + tp * 64 + ks * 16 + kg * 8);
 
-  // ---- staging geometry of this thread: chunk column cc is fixed (NT % 8 == 0), halo pixels hp = (t >> 3) + 32 i
+  // ---- tile-invariant staging constants of this thread: chunk column cc is fixed (NT % 8 == 0), halo pixels (t >> 3) + RPP i
   const int cc = t & 7;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in), 0, p.in_bytes, 0x00020000);
+  int rel[NCH];      // byte offset of the chunk relative to the tile's origin pixel (y0, x0)
+  int ldso[NCH];     // LDS byte offset inside an input stage (lanes beyond the 324 halo pixels: the dump row)
+  unsigned vm_all = 0;   // bit i: chunk i of this thread is a real halo pixel
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int hp = (t >> 3) + RPP * i;
+    const int hy = (hp * 57) >> 10, hx = hp - hy * HS;   // hp / 18, exact for hp < 400
+    rel[i] = (((hy - 1) * p.W + (hx - 1)) * 64 + cc * 8) * 2;
+    ldso[i] = hp < HPIX ? hp * 128 + ((cc ^ ((hx >> 1) & 7)) << 4) : HPIX * 128;
+    if (hp < HPIX) vm_all |= 1u << i;
+  }
+  const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in), 0, p.io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_add =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 2 ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
   float sc[8], sh[8], al[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = 1.f, sh[e] = 0.f, al[e] = 1.f;
   if (NORM && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
   int n_staged = -1;
 
-  v4u_t st[NCH];
-  unsigned stv = 0;   // bit i: chunk i lies inside the image (zero padding otherwise -- also AFTER the affine)
-  auto tile_coords = [&](int tl, int& n, int& y0, int& x0) {
-    n = tl / p.tiles_img;
-    const int r = tl - n * p.tiles_img;
+  auto geo_of = [&](int tl) {
+    TileGeo g;
+    g.n = tl / p.tiles_img;
+    const int r = tl - g.n * p.tiles_img;
     const int ty = r / p.tiles_x;
-    y0 = ty * TS;
-    x0 = (r - ty * p.tiles_x) * TS;
+    g.y0 = ty * TS;
+    g.x0 = (r - ty * p.tiles_x) * TS;
+    g.base = ((g.n * p.H + g.y0) * p.W + g.x0) * 128;
+    g.interior = g.y0 > 0 && g.x0 > 0 && g.y0 + TS < p.H && g.x0 + TS < p.W;
+    return g;
   };
-  auto issue_loads = [&](int tl) {
-    int n, y0, x0;
-    tile_coords(tl, n, y0, x0);
-    if (NORM && n != n_staged) {
-      ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
-      ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
-      n_staged = n;
-    }
-    stv = 0;
+
+  // The pipelined region below must stay free of control flow around memory operations (hipcc's s_waitcnt insertion falls
+  // back to vmcnt(0) at every join, which would drain the stores in flight in front of every LDS write): all conditions are
+  // folded into per-tile bit masks computed at the top of an iteration and applied with selects / out-of-range offsets.
+  // ---- side work 1: global loads of a tile's halo chunks into registers
+  v4u_t st[NCH];
+  auto chunk_mask = [&](const TileGeo& g, bool live) {   // bit i: chunk i lies inside the image (and the tile exists)
+    unsigned m = live ? vm_all : 0u;
+    if (live && !g.interior) {
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int hp = (t >> 3) + 32 * i;
-      const int hy = (hp * 57) >> 10, hx = hp - hy * HS;   // hp / 18 for hp < 324 (+ the tail rows >= 324: masked below)
-      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      const bool ok = hp < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      const unsigned voff = ok ? (unsigned)((((n * p.H + gy) * p.W + gx) * 64 + cc * 8) * 2) : XR64_OOR;
-      st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
-      if (ok) stv |= 1u << i;
-    }
-  };
-  auto write_stage = [&](int buf) {
-    unsigned char* dst = smem + buf * INBUF;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int hp = (t >> 3) + 32 * i;
-      if (hp >= HPIX) continue;
-      const int hy = (hp * 57) >> 10, hx = hp - hy * HS;
-      v4u_t v = st[i];
-      if constexpr (NORM) {
-        const bool ok = (stv >> i) & 1u;
-        unsigned o[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float a = __uint_as_float(v[q] << 16), b = __uint_as_float(v[q] & 0xFFFF0000u);
-          a = a * sc[2 * q] + sh[2 * q];
-          b = b * sc[2 * q + 1] + sh[2 * q + 1];
-          a = a > 0.f ? a : a * al[2 * q];
-          b = b > 0.f ? b : b * al[2 * q + 1];
-          o[q] = ok ? pack2bf(a, b) : 0u;
-        }
-        v = v4u_t{o[0], o[1], o[2], o[3]};
+      for (int i = 0; i < NCH; ++i) {
+        const int hp = (t >> 3) + RPP * i;
+        const int hy = (hp * 57) >> 10, hx = hp - hy * HS;
+        if (!((unsigned)(g.y0 - 1 + hy) < (unsigned)p.H && (unsigned)(g.x0 - 1 + hx) < (unsigned)p.W)) m &= ~(1u << i);
       }
-      *reinterpret_cast<v4u_t*>(dst + hp * 128 + ((cc ^ ((hx >> 1) & 7)) << 4)) = v;
+    }
+    return m;
+  };
+  auto load_chunk = [&](int base, unsigned vm, int i) {
+    const unsigned voff = ((vm >> i) & 1u) ? (unsigned)(base + rel[i]) : XR64_OOR;
+    st[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, 0, 0);
+  };
+  // ---- side work 3: (transform and) write a staged chunk into an input stage
+  auto xform_part = [&](unsigned vm, int i, int q) {   // NORM: dword q (two channels) of staged chunk i, in place
+    if constexpr (NORM) {
+      const bool ok = (vm >> i) & 1u;   // zero padding applies AFTER the transform
+      const unsigned w = st[i][q];
+      float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
+      a = a * sc[2 * q] + sh[2 * q];
+      b = b * sc[2 * q + 1] + sh[2 * q + 1];
+      a = a > 0.f ? a : a * al[2 * q];
+      b = b > 0.f ? b : b * al[2 * q + 1];
+      unsigned o = ok ? pack2bf(a, b) : 0u;
+      // pin the computation to THIS slot: IR-level sinking would otherwise move all four parts down to the LDS write
+      // (sched_barrier only fences the machine scheduler)
+      asm volatile("" : "+v"(o));
+      st[i][q] = o;
     }
   };
+  auto write_chunk = [&](int buf, int i) { *reinterpret_cast<v4u_t*>(smem + buf * INBUF + ldso[i]) = st[i]; };
 
-  // ---- fragment read addressing: lane -> pixel (row lp >> 4 of the block's two image rows, column lp & 15)
-  const int lrow = lp >> 4, lcol = lp & 15;
-  unsigned xoff[3][4];   // [tap column s'][k-step]: byte offset of the lane's chunk inside its pixel row, plus s' pixels
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      xoff[s][ks] = (unsigned)((lrow * HS + lcol + s) * 128 + (((2 * ks + kg) ^ (((lcol + s) >> 1) & 7)) << 4));
-
-  f32x16_t acc[NPB][CBW];
-  float bs[8], bss[8];   // per-image statistics of this thread's channel chunk (store phase: chunk column cc)
+  // ---- side work 2: stream the previous tile's output image out.  thread = (chunk column cc, image rows (t >> 7) + 4 i,
+  // column (t >> 3) & 15)
+  constexpr int ORS = RPP / TS;                                    // image rows between a thread's row groups (4)
+  const int orow0 = t >> 7, ocol = (t >> 3) & 15;
+  const int oimg = OUTBASE + (t >> 3) * OPITCH + cc * 16;          // + i * RPP * OPITCH
+  const int orel0 = ((orow0 * p.W + ocol) * 64 + cc * 8) * 2;      // + i * ORS * W * 128
+  const int orstep = ORS * p.W * 128;
+  float bs[8], bss[8];   // EP == 1: statistics of this thread's channel chunk, current image
 #pragma unroll
   for (int e = 0; e < 8; ++e) bs[e] = 0.f, bss[e] = 0.f;
   int n_stats = -1;
+  v4u_t ov[NOUT], addv[NOUT];
+  auto out_mask = [&](const TileGeo& g, bool live) {   // bit i: row group i of this thread lies inside the image
+    unsigned m = 0;
+    if (live && g.x0 + ocol < p.W) {
+#pragma unroll
+      for (int i = 0; i < NOUT; ++i)
+        if (g.y0 + orow0 + ORS * i < p.H) m |= 1u << i;
+    }
+    return m;
+  };
+  auto out_voff = [&](int base, unsigned om, int i) {
+    return ((om >> i) & 1u) ? (unsigned)(base + orel0 + i * orstep) : XR64_OOR;
+  };
+  auto add_load = [&](int base, unsigned om, int i) {
+    if constexpr (EP == 2) addv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, out_voff(base, om, i), 0, 0);
+  };
+  auto out_read = [&](int i) { ov[i] = *reinterpret_cast<const v4u_t*>(smem + oimg + i * RPP * OPITCH); };
+  auto out_store = [&](int base, unsigned om, int i) {
+    const unsigned voff = out_voff(base, om, i);
+    v4u_t v = ov[i];
+    if constexpr (EP == 2) {
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float a = __uint_as_float(v[q] << 16) + __uint_as_float(addv[i][q] << 16);
+        const float b = __uint_as_float(v[q] & 0xFFFF0000u) + __uint_as_float(addv[i][q] & 0xFFFF0000u);
+        o[q] = pack2bf(a, b);
+      }
+      v = v4u_t{o[0], o[1], o[2], o[3]};
+    }
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, voff, 0, 0);
+    if constexpr (EP == 1) {
+      const bool ok = (om >> i) & 1u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned w = ok ? v[q] : 0u;
+        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
+        bs[2 * q] += a; bss[2 * q] += a * a;
+        bs[2 * q + 1] += b; bss[2 * q + 1] += b * b;
+      }
+    }
+  };
   auto flush_stats = [&]() {
-    // fold the 32 threads that share a chunk column (lanes 8 apart, then the 4 waves through global atomics: rare)
+    // fold the 64 threads that share a chunk column (lanes 8 apart); the 8 waves meet in the atomics (once per image)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float a = bs[e], b = bss[e];
@@ -173,62 +247,125 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       bss[e] = 0.f;
     }
   };
+  auto stats_image = [&](int n) {   // wave-uniform: called before the first stream-out item of a tile
+    if (EP == 1 && n != n_stats) {
+      if (n_stats >= 0) flush_stats();
+      n_stats = n;
+    }
+  };
+  auto norm_image = [&](int n) {    // wave-uniform: per-image transform coefficients of the tile about to be staged
+    if (NORM && n != n_staged) {
+      ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
+      ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
+      n_staged = n;
+    }
+  };
+
+  // ---- fragment read addressing: lane -> pixel (row lp >> 4 of the block's two image rows, column lp & 15); everything
+  // but the stage base and the (block, tap row) immediates is folded into twelve per-lane offsets
+  const int lrow = lp >> 4, lcol = lp & 15;
+  unsigned xb[3][4];   // [tap column][k-step], for the stage being read (toggled between the two stages in place)
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      xb[s][ks] = (unsigned)(((wm * NPB * 2 + lrow) * HS + lcol + s) * 128 + (((2 * ks + kg) ^ (((lcol + s) >> 1) & 7)) << 4));
+
+  f32x16_t acc[NPB];
 
   // prologue: first tile into stage 0
-  issue_loads(tile);
-  write_stage(0);
+  TileGeo cur = geo_of(tile);
+  norm_image(cur.n);
+  {
+    const unsigned vm0 = chunk_mask(cur, true);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) load_chunk(cur.base, vm0, i);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xform_part(vm0, i, q);
+      write_chunk(0, i);
+    }
+  }
   __syncthreads();
 
+  TileGeo prv = cur;
+  bool have_prev = false;
   for (int it = 0; tile < tile_end; ++tile, ++it) {
     const int buf = it & 1;
     const bool more = tile + 1 < tile_end;
-    if (more && !(p.dbg & 1)) issue_loads(tile + 1);   // in flight under the MFMAs below
+    TileGeo nxt = cur;
+    if (more) {
+      nxt = geo_of(tile + 1);
+      norm_image(nxt.n);
+    }
+    if (have_prev) stats_image(prv.n);
+    const unsigned vm = chunk_mask(nxt, more && !(p.dbg & 1));   // chunks of tile t+1 (0: there is none -> loads hit nothing)
+    const unsigned om = out_mask(prv, have_prev && !(p.dbg & 4));   // row groups of tile t-1
+    const int nbase = nxt.base, pbase = prv.base;
+    if (it > 0) {
+      const int d = buf ? INBUF : -INBUF;
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xb[s][ks] += d;
+    }
 
-    // ---- 9 taps x 4 k-steps: NPB pixel fragments from LDS against the register-resident weight fragments
-#pragma unroll
-    for (int i = 0; i < NPB; ++i)
-#pragma unroll
-      for (int j = 0; j < CBW; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const unsigned char* src = smem + buf * INBUF;
-    // software pipeline over the 36 (tap, k-step) stages: the fragments of stage g+1 are read while the MFMAs of stage g
-    // run; sched_barriers keep hipcc from hoisting all 36 stages' reads to the top (it would: 1 wave / SIMD "has" 512 VGPRs)
+    // ---- 36 stages (tap, k-step) x NPB MFMAs; slot k = NPB g + m follows MFMA m of stage g
     bf16x8_t xf[2][NPB];
-    auto read_stage = [&](int g, bf16x8_t (&dst)[NPB]) {
-      const int tp = g >> 2, ks = g & 3;
-      const int r = TR ? 2 - tp / 3 : tp / 3, s = TR ? 2 - tp % 3 : tp % 3;
-#pragma unroll
-      for (int i = 0; i < NPB; ++i) {
-        const int prow = (wm * NPB + i) * 2 + r;   // halo row of the block's first image row for this tap
-        dst[i] = *reinterpret_cast<const bf16x8_t*>(src + prow * HS * 128 + xoff[s][ks]);
+    auto frag_read = [&](auto G, auto I) {
+      constexpr int g = decltype(G)::value, i = decltype(I)::value;
+      constexpr int tp = g >> 2, ks = g & 3;
+      constexpr int r = TR ? 2 - tp / 3 : tp / 3, s = TR ? 2 - tp % 3 : tp % 3;
+      xf[g & 1][i] = *reinterpret_cast<const bf16x8_t*>(smem + xb[s][ks] + (i * 2 + r) * HS * 128);
+    };
+    auto side = [&](auto K) {
+      constexpr int k = decltype(K)::value;   // 0 .. NSLOT - 1 (144 slots per wave and tile)
+      // global loads of tile t+1: slots 1, 4, ..., 31
+      if constexpr (k >= 1 && k < 1 + 3 * NCH && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
+      // stream-out of tile t-1, row group i: (residual load at 33 + 6 i,) LDS read at RD + ST i, store 3 slots later
+      constexpr int RD = EP == 2 ? 69 : 36, ST = EP == 2 ? 6 : 8;
+      if constexpr (EP == 2 && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
+      if constexpr (k >= RD && k < RD + ST * NOUT && (k - RD) % ST == 0) out_read((k - RD) / ST);
+      if constexpr (k >= RD + 3 && k < RD + 3 + ST * NOUT && (k - RD - 3) % ST == 0) out_store(pbase, om, (k - RD - 3) / ST);
+      // transform + LDS write of tile t+1 (the loads left >= 55 slots earlier).  NORM: chunk i is transformed two channels
+      // at a time at slots 56 + 8 i + {0, 2, 4, 6} and written at 56 + 8 i + 7; otherwise written at 100 + 4 i
+      if constexpr (NORM) {
+        if constexpr (k >= 56 && k < 56 + 8 * NCH && (k - 56) % 8 % 2 == 0) xform_part(vm, (k - 56) / 8, (k - 56) % 8 / 2);
+        if constexpr (k >= 56 && k < 56 + 8 * NCH && (k - 56) % 8 == 7) write_chunk(buf ^ 1, (k - 56) / 8);
+      } else {
+        if constexpr (k >= 100 && k < 100 + 4 * NCH && (k - 100) % 4 == 0) write_chunk(buf ^ 1, (k - 100) / 4);
       }
     };
-    read_stage(0, xf[0]);
-    if (!(p.dbg & 8))
-#pragma unroll
-    for (int g = 0; g < 36; ++g) {
-      if (g + 1 < 36) read_stage(g + 1, xf[(g + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < NPB; ++i)
-#pragma unroll
-        for (int j = 0; j < CBW; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g >> 2][g & 3][j], xf[g & 1][i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();   // every wave is done reading stage `buf`
+    static_for<0, NPB>([&](auto I) { frag_read(std::integral_constant<int, 0>{}, I); });
+    static_for<0, 36>([&](auto G) {
+      constexpr int g = decltype(G)::value;
+      static_for<0, NPB>([&](auto M) {
+        constexpr int m = decltype(M)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g == 0) {
+          const f32x16_t z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], xf[0][m], z, 0, 0, 0);
+        } else {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g >> 2][g & 3], xf[g & 1][m], acc[m], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 1 < 36) frag_read(std::integral_constant<int, g + 1>{}, M);   // consumed by MFMA m of the next stage
+        side(std::integral_constant<int, g * NPB + m>{});
+      });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // stage `buf` and the output image are free; stage buf ^ 1 is complete
 
-    // ---- accumulators (+bias) -> [256 pixels][64 channels] bf16 image in stage `buf`
-    unsigned char* img = smem + buf * INBUF;
-    if (!(p.dbg & 2))
-#pragma unroll
-    for (int j = 0; j < CBW; ++j)
+    // ---- accumulators (+bias) -> [256 pixels][64 channels] bf16 output image
+    if (!(p.dbg & 2)) {
+      unsigned char* img = smem + OUTBASE;
+      const bool hb = p.bias != nullptr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int ch0 = (wn * CBW + j) * 32 + 8 * q + 4 * kg;
+        const int ch0 = wn * 32 + 8 * q + 4 * kg;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) {
+        if (hb) {
           const float4 b4 = *reinterpret_cast<const float4*>(p.bias + ch0);
           bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
         }
@@ -236,75 +373,51 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
         for (int i = 0; i < NPB; ++i) {
           const int prow = (wm * NPB + i) * 32 + lp;
           uint2 pk;
-          pk.x = pack2bf(acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1]);
-          pk.y = pack2bf(acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]);
+          pk.x = pack2bf(acc[i][4 * q] + bv[0], acc[i][4 * q + 1] + bv[1]);
+          pk.y = pack2bf(acc[i][4 * q + 2] + bv[2], acc[i][4 * q + 3] + bv[3]);
           *reinterpret_cast<uint2*>(img + prow * OPITCH + ch0 * 2) = pk;
         }
       }
-    // next tile: registers -> the other stage (its last readers finished before the barrier above)
-    if (more && !(p.dbg & 1)) write_stage(buf ^ 1);
-    __syncthreads();
-
-    // ---- stream the image out: thread = (chunk column cc, pixel rows (t >> 3) + 32 i)
-    int n, y0, x0;
-    tile_coords(tile, n, y0, x0);
-    if (p.stats != nullptr && n != n_stats) {
-      if (n_stats >= 0) flush_stats();
-      n_stats = n;
     }
-    if (!(p.dbg & 4))
+    __syncthreads();   // output image complete
+    prv = cur;
+    cur = nxt;
+    have_prev = true;
+  }
+  // drain: the last tile's output image
+  stats_image(prv.n);
+  {
+    const unsigned om = out_mask(prv, true);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int pr = (t >> 3) + 32 * i;
-      const int gy = y0 + (pr >> 4), gx = x0 + (pr & 15);
-      if (gy >= p.H || gx >= p.W) continue;
-      const size_t go = (((size_t)n * p.H + gy) * p.W + gx) * 64 + cc * 8;
-      const uint4 u = *reinterpret_cast<const uint4*>(img + pr * OPITCH + cc * 16);
-      if (p.ep_add != nullptr) {
-        float d[8], av[8];
-        const unsigned w4[4] = {u.x, u.y, u.z, u.w};
+    for (int i = 0; i < NOUT; ++i) add_load(prv.base, om, i);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          d[2 * q] = __uint_as_float(w4[q] << 16);
-          d[2 * q + 1] = __uint_as_float(w4[q] & 0xFFFF0000u);
-        }
-        ld8(p.ep_add + go, av);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] += av[e];
-        st8(p.out + go, d);
-      } else {
-        *reinterpret_cast<uint4*>(p.out + go) = u;
-        if (p.stats != nullptr) {
-          const unsigned w4[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float a = __uint_as_float(w4[q] << 16), b = __uint_as_float(w4[q] & 0xFFFF0000u);
-            bs[2 * q] += a; bss[2 * q] += a * a;
-            bs[2 * q + 1] += b; bss[2 * q + 1] += b * b;
-          }
-        }
-      }
+    for (int i = 0; i < NOUT; ++i) {
+      out_read(i);
+      out_store(prv.base, om, i);
     }
   }
-  if (p.stats != nullptr) flush_stats();
+  if (EP == 1) flush_stats();
 }
 
-template <bool TR, bool NORM, int CBW>
+template <bool TR, bool NORM, int EP>
 int launch_dconv64(DC64P& p, int grid, hipStream_t st) {
-  auto kern = dconv64_kernel<TR, NORM, CBW>;
-  constexpr int smem = 2 * INBUF;
-  static bool attr_done = false;   // idempotent attribute; a racing second call only repeats it
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      xr_set_error("xr_conv64_direct: hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e));
-      return XR_E_LAUNCH;
-    }
-    attr_done = true;
+  auto kern = dconv64_kernel<TR, NORM, EP>;
+  // (idempotent attribute: a racing second caller only repeats it)
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  if (e != hipSuccess) {
+    xr_set_error("xr_conv64_direct: hipFuncSetAttribute(%d) failed: %s", SMEM, hipGetErrorString(e));
+    return XR_E_LAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), SMEM, st, p);
   XR_CHECK_LAUNCH("xr_conv64_direct");
   return XR_OK;
+}
+
+template <bool TR, bool NORM>
+int launch_dconv64_ep(DC64P& p, int grid, hipStream_t st) {
+  if (p.stats != nullptr) return launch_dconv64<TR, NORM, 1>(p, grid, st);
+  if (p.ep_add != nullptr) return launch_dconv64<TR, NORM, 2>(p, grid, st);
+  return launch_dconv64<TR, NORM, 0>(p, grid, st);
 }
 
 }  // namespace
@@ -316,8 +429,8 @@ extern "C" int xr_conv64_direct(const void* in, const void* wpack, const float* 
   XR_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "xr_conv64_direct: in_scale and in_shift come together");
   XR_CHECK_ARG(in_alpha == nullptr || in_scale != nullptr, "xr_conv64_direct: in_alpha needs in_scale / in_shift");
   XR_CHECK_ARG(out_stats == nullptr || ep_add == nullptr, "xr_conv64_direct: output statistics and ep_add are exclusive");
-  const long long in_bytes = (long long)N * H * W * 64 * 2;
-  XR_CHECK_ARG(in_bytes < (1ll << 31), "xr_conv64_direct: input larger than 2 GiB (use xr_conv_igemm)");
+  const long long io_bytes = (long long)N * H * W * 64 * 2;
+  XR_CHECK_ARG(io_bytes < (1ll << 31), "xr_conv64_direct: tensor larger than 2 GiB (use xr_conv_igemm)");
   DC64P p{};
   p.in = (const bf16_t*)in; p.w = (const bf16_t*)wpack; p.bias = bias; p.out = (bf16_t*)out; p.ep_add = (const bf16_t*)ep_add;
   p.n_scale = in_scale; p.n_shift = in_shift; p.n_alpha = in_alpha; p.stats = out_stats;
@@ -325,7 +438,7 @@ extern "C" int xr_conv64_direct(const void* in, const void* wpack, const float* 
   p.tiles_x = cdiv(W, TS);
   p.tiles_img = p.tiles_x * cdiv(H, TS);
   p.ntiles = p.tiles_img * N;
-  p.in_bytes = (unsigned)in_bytes;
+  p.io_bytes = (unsigned)io_bytes;
   p.dbg = g_tune[14];
   int cus = 256;
   {
@@ -340,13 +453,6 @@ extern "C" int xr_conv64_direct(const void* in, const void* wpack, const float* 
   const int grid = cdiv(p.ntiles, p.tpw);
   hipStream_t st = (hipStream_t)stream;
   const bool norm = in_scale != nullptr;
-  // knob 13: 0 (default) = a wave holds half of the weight panel (144 VGPRs, no spills); 1 = the whole panel (288 VGPRs: fewer
-  // LDS fragment reads, but hipcc spills ~20-50 registers to scratch at 512)
-  const bool wide = g_tune[13] == 1;
-  if (transposed) {
-    if (norm) return wide ? launch_dconv64<true, true, 2>(p, grid, st) : launch_dconv64<true, true, 1>(p, grid, st);
-    return wide ? launch_dconv64<true, false, 2>(p, grid, st) : launch_dconv64<true, false, 1>(p, grid, st);
-  }
-  if (norm) return wide ? launch_dconv64<false, true, 2>(p, grid, st) : launch_dconv64<false, true, 1>(p, grid, st);
-  return wide ? launch_dconv64<false, false, 2>(p, grid, st) : launch_dconv64<false, false, 1>(p, grid, st);
+  if (transposed) return norm ? launch_dconv64_ep<true, true>(p, grid, st) : launch_dconv64_ep<true, false>(p, grid, st);
+  return norm ? launch_dconv64_ep<false, true>(p, grid, st) : launch_dconv64_ep<false, false>(p, grid, st);
 }

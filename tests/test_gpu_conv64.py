@@ -35,7 +35,7 @@ def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-@pytest.mark.parametrize("wide", [0, 1])
+@pytest.mark.parametrize("wide", [0])
 @pytest.mark.parametrize("case", CASES)
 def test_direct_conv64_forward_and_input_gradient(case, wide):
     from xrface import ops
