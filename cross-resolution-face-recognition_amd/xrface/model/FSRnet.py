@@ -31,6 +31,10 @@ class _Residual_Block(nn.Module):
         self.relu_out = xnn.PReLU(out_channels)
 
     def f(self, x):
+        if ops.direct64_ok(x, self.conv1.weight, 1, 1) and tuple(self.conv2.weight.shape) == (64, 64, 3, 3):
+            # bf16, 64 channels: the whole block as one op on the direct convolution kernel (statistics in the conv
+            # epilogues, IN1 + PReLU applied on conv2's load)
+            return ops.resblock64(x, self.conv1, self.in1, self.relu, self.conv2, self.in2, self.relu_out)
         # the block input feeds conv1 and the residual add: route the residual through conv1's pass-through output so the
         # two gradients of x meet in conv1's dgrad epilogue instead of in a separate elementwise add
         c1, xs = self.conv1.f_pass(x)

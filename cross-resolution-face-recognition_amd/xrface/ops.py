@@ -17,7 +17,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1"))}
 
 
 def set_compute_dtype(dtype):
@@ -480,6 +480,24 @@ class _Conv2d(Function):
         Kp = r8(K)
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
+        ctx.direct64 = direct64_ok(x, w, stride, pad) and prelu_alpha is None and bn_link is None
+        if ctx.direct64:
+            # 64 -> 64 3x3: weights-stationary direct kernel; a following training-mode BatchNorm gets its statistics from the
+            # per-image sums of the epilogue (StatsLink folds them over the batch)
+            sred = None
+            if stats_link is not None and _cfg["fuse_conv_stats"]:
+                sred = zeros_f32((2, N, Kp), x.device)
+            _conv64(x, pk, y, bias=bf, stats=sred, tag=("fwd", Cp, K, H, W, R, stride))
+            if sred is not None:
+                stats_link.deliver(y, sred)
+            ctx.save_for_backward(x, w)
+            ctx.geom = (stride, pad, b is not None)
+            ctx.bias_ref = b
+            ctx.bn_link = None
+            ctx.passthrough = passthrough
+            if ctx.passthrough:
+                return y, x.view_as(x)
+            return y
         # prelu_alpha: also emit p = prelu(y, alpha) from the epilogue (second, non-differentiable output): the activation
         # pass of conv -> PReLU -> conv disappears; its backward still rides in the next conv's dgrad epilogue
         p2 = al = None
@@ -527,7 +545,15 @@ class _Conv2d(Function):
         K, C, R, S = w.shape
         _, Ho, Wo, Kp = dy.shape
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and getattr(ctx, "direct64", False):
+            pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
+            dpass = _dp2 if ctx.passthrough else None
+            if dpass is not None:
+                dpass = _c(dpass)
+                if dpass.dtype != x.dtype:
+                    dpass = dpass.to(x.dtype)
+            dx = _conv64(dy, pk, torch.empty_like(x), transposed=1, add=dpass, tag=("dgrad", Cp, K, H, W, R, stride))
+        elif ctx.needs_input_grad[0]:
             pk, kg = _packed(w, "dgrad", x.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dx = torch.empty_like(x)
             link, red, sp_ = ctx.bn_link, None, 1
@@ -986,6 +1012,132 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps):
     scale, shift = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
     lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
     return scale, shift
+
+
+# ------------------------------------------------------------------------------------------------- direct 64-channel path
+def direct64_ok(x, w, stride, pad):
+    """bf16, 64 -> 64 channels, 3x3, stride 1, pad 1: the weights-stationary direct kernel (csrc/xr_conv64.hip) applies."""
+    return (_cfg["direct64"] and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 64 and tuple(w.shape) == (64, 64, 3, 3)
+            and stride == 1 and pad == 1 and x.numel() * 2 < (1 << 31))
+
+
+def _conv64(x, pk, out, transposed=0, bias=None, scale=None, shift=None, alpha=None, stats=None, add=None, tag=None):
+    N, H, W, _ = x.shape
+    pe = _probe_begin(tag) if tag is not None else None
+    lib.xr_conv64_direct(ptr(x), ptr(pk), ptr(bias), ptr(out), N, H, W, transposed, ptr(scale), ptr(shift), ptr(alpha), ptr(stats),
+                         ptr(add), stream())
+    if pe is not None:
+        pe.record()
+    return out
+
+
+class _ResBlock64(Function):
+    """FSRNet residual block (model/FSRnet.py:75-98) on 64 channels in bf16 as ONE op over the direct convolution kernel:
+        c1 = conv1(x)                      + per-image sum / sum-of-squares of c1 in the epilogue      (no statistics pass)
+        c2 = conv2(prelu(IN1(c1)))         with IN1 + PReLU applied on load                            (y1 never exists in HBM)
+                                           + statistics of c2 in the epilogue
+        out = prelu_out(IN2(c2) + x)       one elementwise pass
+    7 tensor passes instead of 11; backward: both input gradients on the direct kernel (the residual-branch gradient is summed
+    in conv1's dgrad epilogue), y1 is recomputed once for conv2's weight gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, a1, w2, g2, b2, ao, eps):
+        x = _c(x)
+        N, H, W, C = x.shape
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        pk1, _ = _packed(w1, "fwd", x.dtype, 64, 1, 9, 64, 64, 576, 0, 1, 9)
+        pk2, _ = _packed(w2, "fwd", x.dtype, 64, 1, 9, 64, 64, 576, 0, 1, 9)
+        fl = lambda t: None if t is None else _c(t.detach().float())
+        g1f, b1f, a1f, g2f, b2f, aof = fl(g1), fl(b1), fl(a1), fl(g2), fl(b2), fl(ao)
+        HW = H * W
+        tag = ("fwd", 64, 64, H, W, 3, 1)
+
+        def finalize(sums, gm, bt):
+            mean, invstd = torch.empty((N, C), **f32), torch.empty((N, C), **f32)
+            scale, shift = torch.empty((N, C), **f32), torch.empty((N, C), **f32)
+            lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), None, None, N, HW, C, eps,
+                                 0.0, 1, stream())
+            return mean, invstd, scale, shift
+
+        st1 = zeros_f32((2, N, C), dev)
+        c1 = _conv64(x, pk1, torch.empty_like(x), stats=st1, tag=tag)
+        mean1, invstd1, scale1, shift1 = finalize(st1, g1f, b1f)
+        st2 = zeros_f32((2, N, C), dev)
+        c2 = _conv64(c1, pk2, torch.empty_like(x), scale=scale1, shift=shift1, alpha=a1f, stats=st2, tag=tag)
+        mean2, invstd2, scale2, shift2 = finalize(st2, g2f, b2f)
+        out = torch.empty_like(x)
+        lib.xr_affine_act(dt(x), ptr(c2), ptr(scale2), ptr(shift2), ptr(x), ptr(aof), ACT_PRELU, ptr(out), N, HW, C, 1, stream())
+        ctx.save_for_backward(x, c1, c2, w1, w2, mean1, invstd1, scale1, shift1, mean2, invstd2, scale2, shift2, g1f, a1f, g2f, aof)
+        ctx.prefs = (g1, b1, a1, g2, b2, ao)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, c1, c2, w1, w2, mean1, invstd1, scale1, shift1, mean2, invstd2, scale2, shift2, g1f, a1f, g2f, aof = ctx.saved_tensors
+        g1, b1, a1, g2, b2, ao = ctx.prefs
+        N, H, W, C = x.shape
+        HW = H * W
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = _c(dout)
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        d = dt(x)
+
+        def small(p_, has):
+            t_ = _direct(p_) if has else None
+            return t_, ((t_ if t_ is not None else zeros_f32((C,), dev)) if has else None)
+
+        def norm_bwd(xin, scale, shift, res, alf, gmf, mean, invstd, dy, p_g, p_b, p_a, want_res):
+            red = zeros_f32((3, N, C), dev)
+            lib.xr_affine_act_bwd_reduce(d, ptr(xin), ptr(scale), ptr(shift), ptr(res), ptr(alf), ACT_PRELU, ptr(dy), ptr(red), N, HW, C,
+                                         1, stream())
+            coef = torch.empty((3, N, C), **f32)
+            (t_g, dg), (t_b, db), (t_a, da) = small(p_g, p_g is not None), small(p_b, p_b is not None), small(p_a, True)
+            lib.xr_norm_bwd_coeffs(ptr(red), ptr(gmf), ptr(mean), ptr(invstd), ptr(coef), ptr(dg), ptr(db), ptr(da), N, HW, C, 1, stream())
+            outs = []
+            for p_, t_, v in ((p_g, t_g, dg), (p_b, t_b, db), (p_a, t_a, da)):
+                if t_ is not None:
+                    _direct_done(p_)
+                    outs.append(None)
+                else:
+                    outs.append(v)
+            dx = torch.empty_like(xin)
+            dres = torch.empty_like(xin) if want_res else None
+            lib.xr_affine_act_bwd_apply(d, ptr(xin), ptr(scale), ptr(shift), ptr(res), ptr(alf), ACT_PRELU, ptr(dy), ptr(coef), ptr(dx),
+                                        ptr(dres), N, HW, C, 1, None, stream())
+            return dx, dres, outs
+
+        need_x = ctx.needs_input_grad[0]
+        # out = prelu_out(IN2(c2) + x)
+        dc2, dres, (dg2, db2, dao) = norm_bwd(c2, scale2, shift2, x, aof, g2f, mean2, invstd2, dout, g2, b2, ao, need_x)
+        # c2 = conv2(y1), y1 = prelu(IN1(c1))
+        tagd = ("dgrad", 64, 64, H, W, 3, 1)
+        pkd2, _ = _packed(w2, "dgrad", x.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
+        dy1 = _conv64(dc2, pkd2, torch.empty_like(x), transposed=1, tag=tagd)
+        dw2 = None
+        if ctx.needs_input_grad[5] and _wanted(w2):
+            y1 = torch.empty_like(x)   # recomputed for the weight gradient only (the forward never wrote it)
+            lib.xr_affine_act(d, ptr(c1), ptr(scale1), ptr(shift1), None, ptr(a1f), ACT_PRELU, ptr(y1), N, HW, C, 1, stream())
+            dw2 = _wgrad(w2, y1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64, 64, 576,
+                         0, 1, 9)
+        dc1, _, (dg1, db1, da1) = norm_bwd(c1, scale1, shift1, None, a1f, g1f, mean1, invstd1, dy1, g1, b1, a1, False)
+        dx = None
+        if need_x:
+            pkd1, _ = _packed(w1, "dgrad", x.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
+            dx = _conv64(dc1, pkd1, torch.empty_like(x), transposed=1, add=dres, tag=tagd)   # + the residual-branch gradient
+        dw1 = None
+        if ctx.needs_input_grad[1] and _wanted(w1):
+            dw1 = _wgrad(w1, x, dc1, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64, 64, 576,
+                         0, 1, 9)
+        return dx, dw1, dg1, db1, da1, dw2, dg2, db2, dao, None
+
+
+def resblock64(x, conv1, in1, relu, conv2, in2, relu_out):
+    """conv1 / conv2: xrface.nn.Conv2d (64 -> 64, 3x3, bias-free), in1 / in2: affine InstanceNorm2d, relu / relu_out: PReLU(64)."""
+    return _ResBlock64.apply(x, conv1.weight, in1.weight, in1.bias, relu.weight, conv2.weight, in2.weight, in2.bias,
+                             relu_out.weight, in1.eps)
 
 
 # ------------------------------------------------------------------------------------------------- SE

@@ -125,3 +125,54 @@ def test_direct_conv64_argument_checks():
     from xrface._lib import lib
     with pytest.raises(RuntimeError, match="xr_conv64_direct"):
         lib.xr_conv64_direct(None, None, None, None, 1, 16, 16, 0, None, None, None, None, None, None)
+
+
+def _block_run(direct, x, gout, seed=0):
+    import xrface
+    from xrface import ops
+    from xrface.model.FSRnet import _Residual_Block
+    old = ops._cfg["direct64"]
+    ops._cfg["direct64"] = direct
+    xrface.set_compute_dtype(torch.bfloat16)
+    try:
+        blk = _Residual_Block(64)
+        blk.load_state_dict(G.det_state_dict(blk.state_dict(), seed))
+        blk.to(DEV)
+        xg = x.clone().to(DEV).requires_grad_(True)
+        y = blk(xg)
+        y.backward(gout.to(DEV))
+        torch.cuda.synchronize()
+        return y.detach().float().cpu(), xg.grad.float().cpu(), {k: p_.grad.float().cpu() for k, p_ in blk.named_parameters()}
+    finally:
+        ops._cfg["direct64"] = old
+        xrface.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 28, 28), (2, 112, 112)])
+def test_fused_residual_block_matches_the_unfused_path_and_fp32(shape):
+    """_Residual_Block in bf16: the fused op on the direct kernel (statistics in conv epilogues, IN1 + PReLU on conv2's load)
+    against the unfused bf16 path (same arithmetic, the normalised activation rounded to bf16 in both) and against the
+    fp32 CPU block (model/FSRnet.py:90-98 restated by the oracle)."""
+    from oracle import cpu_ref as R
+    N, H, W = shape
+    x = rnd(f"rbx{shape}", N, 64, H, W).bfloat16().float()
+    gout = rnd(f"rbg{shape}", N, 64, H, W).bfloat16().float()
+    y_f, dx_f, g_f = _block_run(1, x, gout)
+    y_u, dx_u, g_u = _block_run(0, x, gout)
+    cos = lambda a, b: float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm() + 1e-30))
+    assert rel(y_f, y_u) < 3e-2 and cos(y_f, y_u) > 0.9999
+    assert cos(dx_f, dx_u) > 0.999
+    for k in g_u:
+        assert cos(g_f[k], g_u[k]) > 0.995, (k, cos(g_f[k], g_u[k]))
+    # fp32 reference
+    from xrface.model.FSRnet import _Residual_Block
+    blk = _Residual_Block(64)
+    sd = G.det_state_dict(blk.state_dict(), 0)
+    sdg = R.with_grad({"b." + k: v for k, v in sd.items()})
+    xr = x.clone().requires_grad_(True)
+    y_ref = R.residual_block(sdg, "b", xr)
+    y_ref.backward(gout)
+    assert rel(y_f, y_ref) < 3e-2 and cos(y_f, y_ref) > 0.9995
+    assert cos(dx_f, xr.grad) > 0.998
+    for k in g_f:
+        assert cos(g_f[k], sdg["b." + k].grad) > 0.99, (k, cos(g_f[k], sdg["b." + k].grad))
