@@ -4,7 +4,20 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
+#include <mutex>
 #include "xrface.h"
+
+// Launch-configuration selectors (xr_tune): they pick WHICH kernel variant / tile a launcher uses, never what it computes.
+// Relaxed atomics: launchers are called concurrently from autograd worker threads, xr_tune is a test / A-B hook that the
+// product path calls only at library load (XR_TUNE) -- a reader sees either the old or the new selector, never a torn one.
+struct XrTune {
+  std::atomic<int> v;
+  XrTune(int x = 0) : v(x) {}
+  operator int() const { return v.load(std::memory_order_relaxed); }
+  XrTune& operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
+extern XrTune g_tune[16];
 
 typedef unsigned short bf16_t;  // raw bf16 storage
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

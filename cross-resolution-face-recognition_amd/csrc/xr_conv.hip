@@ -589,7 +589,7 @@ constexpr size_t igemm_smem() {
 }
 
 }  // namespace
-int g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
+XrTune g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
 namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>

@@ -29,7 +29,6 @@
 #include "xr_common.h"
 #include <type_traits>
 
-extern int g_tune[16];
 
 namespace {
 

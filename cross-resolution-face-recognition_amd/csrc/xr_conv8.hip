@@ -550,15 +550,16 @@ static int igemm8_launch_cfg2(IgemmP& p, hipStream_t st) {
   const int tiles_m = cdiv(p.M, C8::BMV);
   p.fd_tn = make_fd((unsigned)p.tiles_n);
   constexpr int smem = 2 * C8::BUF;
-  static bool attr_done = false;
   auto kern = igemm8_kernel<TR, WRN, MB, MB1, DEEP>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      xr_set_error("xr_conv_igemm(8-wave): hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(e));
-      return XR_E_LAUNCH;
-    }
-    attr_done = true;
+  // once per template instance, safe from concurrent autograd threads; a failure is remembered and reported on every call
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  });
+  if (attr_err != hipSuccess) {
+    xr_set_error("xr_conv_igemm(8-wave): hipFuncSetAttribute(%d) failed: %s", smem, hipGetErrorString(attr_err));
+    return XR_E_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles_m * p.tiles_n), dim3(NT8), smem, st, p);
   XR_CHECK_LAUNCH("xr_conv_igemm(8-wave)");

@@ -73,7 +73,6 @@ __device__ __forceinline__ void decode_pixel(int m, int M, const FastDiv& fd_how
 }
 
 
-extern int g_tune[16];
 
 // 8-wave 256x256 tile path (xr_conv8.hip).  xr_igemm8_eligible() decides from the problem alone; the launcher returns
 // XR_OK or a negative error code like every other launcher.

@@ -9,7 +9,6 @@
 // 23-46,56-66,76-91,141-148; model/resnet.py:24-47,159,167,173.
 #include "xr_common.h"
 
-extern int g_tune[16];  // [8] xr_group_stats target blocks, [9] xr_affine_act_bwd_reduce target blocks (xr_conv.hip)
 
 namespace {
 

@@ -172,10 +172,39 @@ def _side_done(side, tensors):
             join_side_stream()
 
 
-def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg, split, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
-    """Weight gradient: sliced implicit GEMM into per-slice slabs, then sum + convert to the parameter layout
-    (accumulating straight into ``w.grad`` when direct mode is on)."""
+def _wgrad64_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed):
+    """bf16 64 -> 64 3x3 / stride 1 / pad 1 with W % 8 == 0, W <= 112: the direct weight-gradient kernel (csrc/xr_wgrad64.hip)."""
+    return (_cfg["direct64"] and x.dtype == torch.bfloat16 and Cp == 64 and K == 64 and R == 3 and S == 3 and stride == 1 and pad == 1
+            and not transposed and Ho == H and Wo == W and W % 8 == 0 and W <= 112 and dy.shape[-1] == 64
+            and x.numel() * 2 < (1 << 31))
+
+
+def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg, split, A1, A2, taps, B, Bp, sa1, sa2, st, sb,
+           xform=None):
+    """Weight gradient: sliced implicit GEMM (or, for the 64-channel 3x3 layers, the direct row-walking kernel) into partial
+    slabs, then sum + convert to the parameter layout (accumulating straight into ``w.grad`` when direct mode is on).
+    ``xform`` = (scale [N][64], shift [N][64], alpha [64] or None): x is transformed on load (direct kernel only)."""
     tgt = _direct(w)
+    d64 = _wgrad64_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed)
+    assert xform is None or d64, "on-load transform needs the direct 64-channel weight-gradient kernel"
+    if d64:
+        split = min(256, N * H)
+
+    def launch(slabs, sh, on=None):
+        pe = _probe_begin(("wgrad", Cp, K, H, W, R, stride), on)
+        if d64:
+            sc, sf, al = xform if xform is not None else (None, None, None)
+            ns = lib.xr_conv64_wgrad(ptr(x), ptr(dy), ptr(slabs), N, H, W, split, ptr(sc), ptr(sf), ptr(al), sh)
+        else:
+            ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
+                                   kg, split, sh)
+        if pe is not None:
+            if on is None:
+                pe.record()
+            else:
+                pe.record(on)
+        return ns
+
     # (not while a HIP graph is being captured: graphs stay single-stream -- a captured fork/join brought nothing at the
     # small batch sizes graphs are for, and multi-stream graph teardown is the less-trodden path of the runtime)
     if tgt is not None and _cfg["wgrad_stream"] and not _graph["capturing"]:
@@ -183,21 +212,13 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
         side = _side_fork(dev)     # side stream now waits for everything enqueued on the current stream (x, dy, zeroed grads)
         sh = side.cuda_stream      # launch on the side stream by handle: no current-stream switch on the host
         slabs = torch.empty((split, K, kg), dtype=torch.float32, device=dev)
-        pe = _probe_begin(("wgrad", Cp, K, H, W, R, stride), side)
-        ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
-                               kg, split, sh)
-        if pe is not None:
-            pe.record(side)
+        ns = launch(slabs, sh, side)
         lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, sh)
-        _side_done(side, (x, dy, slabs))
+        _side_done(side, (x, dy, slabs) + (tuple(t for t in xform if t is not None) if xform is not None else ()))
         _direct_done(w)
         return None
     slabs = torch.empty((split, K, kg), dtype=torch.float32, device=x.device)
-    pe = _probe_begin(("wgrad", Cp, K, H, W, R, stride))
-    ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg,
-                           split, stream())
-    if pe is not None:
-        pe.record()
+    ns = launch(slabs, stream())
     if tgt is not None:
         lib.xr_unpack_wgrad(ptr(slabs), ptr(tgt), A1, A2, taps, B, Bp, kg, sa1, sa2, st, sb, 1, ns, stream())
         _direct_done(w)
@@ -1118,10 +1139,15 @@ class _ResBlock64(Function):
         dy1 = _conv64(dc2, pkd2, torch.empty_like(x), transposed=1, tag=tagd)
         dw2 = None
         if ctx.needs_input_grad[5] and _wanted(w2):
-            y1 = torch.empty_like(x)   # recomputed for the weight gradient only (the forward never wrote it)
-            lib.xr_affine_act(d, ptr(c1), ptr(scale1), ptr(shift1), None, ptr(a1f), ACT_PRELU, ptr(y1), N, HW, C, 1, stream())
-            dw2 = _wgrad(w2, y1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64, 64, 576,
-                         0, 1, 9)
+            if _wgrad64_ok(c1, dc2, H, W, 64, H, W, 64, 3, 3, 1, 1, 0):
+                # y1 = prelu(IN1(c1)) is rebuilt ON LOAD by the direct weight-gradient kernel (the forward never wrote it either)
+                dw2 = _wgrad(w2, c1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, 0, 64, 1, 9, 64, 64, 576, 0, 1, 9,
+                             xform=(scale1, shift1, a1f))
+            else:
+                y1 = torch.empty_like(x)   # recomputed for the weight gradient only
+                lib.xr_affine_act(d, ptr(c1), ptr(scale1), ptr(shift1), None, ptr(a1f), ACT_PRELU, ptr(y1), N, HW, C, 1, stream())
+                dw2 = _wgrad(w2, y1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64,
+                             64, 576, 0, 1, 9)
         dc1, _, (dg1, db1, da1) = norm_bwd(c1, scale1, shift1, None, a1f, g1f, mean1, invstd1, dy1, g1, b1, a1, False)
         dx = None
         if need_x:

@@ -127,6 +127,16 @@ int xr_conv64_direct(const void* in, const void* wpack, const float* bias, void*
 int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,
                   int Wo, int K, int R, int S, int stride, int pad, int transposed, int ldy, int Kg, int split,
                   void* stream);
+/* Direct weight gradient of the 64 -> 64 channel 3x3 / stride 1 / pad 1 bf16 layers (same call sites as xr_conv64_direct; bf16 in /
+ * dy [N][H][W][64]): the result xr_conv_wgrad(XR_BF16, ..., C = K = 64, R = S = 3, stride 1, pad 1, ldy = 64, Kg = 576) gives, as
+ * per-workgroup partial slabs [s][64][576] in the same packed layout (sum them with xr_unpack_wgrad).  Every input and dy row is
+ * read from HBM once (persistent workgroups walk image rows, the nine taps are shifted LDS views).  Needs W % 8 == 0, W <= 112.
+ *   in_scale / in_shift [N][64] (+ in_alpha [64], optional): `in` is transformed ON LOAD as in xr_conv64_direct,
+ *     x' = prelu(x * in_scale[n][c] + in_shift[n][c], in_alpha[c]) -- the weight gradient of a convolution whose forward consumed
+ *     the normalised activation without ever writing it (model/FSRnet.py:81-85).
+ * slabs must hold max_slabs * 64 * 576 floats.  RETURNS the number of slabs written (1 <= value <= max_slabs) or a negative XR_E_*. */
+int xr_conv64_wgrad(const void* in, const void* dy, float* slabs, int N, int H, int W, int max_slabs, const float* in_scale,
+                    const float* in_shift, const float* in_alpha, void* stream);
 /* Sum the `nslices` slabs and convert to the parameter layout (inverse of xr_pack_weight):
  * dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= sum_s packed[s][a][t*Bp + b];  accumulate != 0 adds into dst. */
 int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,

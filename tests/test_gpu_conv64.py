@@ -176,3 +176,89 @@ def test_fused_residual_block_matches_the_unfused_path_and_fp32(shape):
     assert cos(dx_f, xr.grad) > 0.998
     for k in g_f:
         assert cos(g_f[k], sdg["b." + k].grad) > 0.99, (k, cos(g_f[k], sdg["b." + k].grad))
+
+
+# ------------------------------------------------------------------------------------------------ direct weight gradient
+WG_CASES = [  # N, H, W
+    (2, 16, 16),      # one 16-pixel chunk per row, more workgroups than rows would allow -> one row each
+    (3, 24, 40),      # non-square, W not a multiple of 16 (40 -> three chunks, the last half empty)
+    (1, 112, 112),    # the FSRNet layer, one image over many workgroups
+    (5, 56, 56),      # IR stage 1
+    (600, 8, 8),      # 4800 rows over 256 workgroups: runs that start and end mid-image
+    (7, 112, 112),    # 784 rows: runs of four rows crossing image boundaries
+]
+
+
+def _unpack(slabs, ns):
+    from xrface._lib import lib, ptr, stream
+    dw = torch.empty(64, 64, 3, 3, device=DEV)
+    lib.xr_unpack_wgrad(ptr(slabs), ptr(dw), 64, 1, 9, 64, 64, 576, 576, 0, 1, 9, 0, ns, stream())
+    return dw
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_direct_wgrad64_matches_fp32_and_the_sliced_kernel(case):
+    """xr_conv64_wgrad vs (a) the fp32 CPU weight gradient of the same bf16-rounded operands, (b) xr_conv_wgrad (the sliced
+    implicit GEMM it replaces: same products, fp32 sums in another order)."""
+    from xrface._lib import lib, ptr, stream
+    N, H, W = case
+    x = rnd(f"wg64x{case}", N, 64, H, W).bfloat16().float()
+    gy = rnd(f"wg64g{case}", N, 64, H, W).bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (64, 64, 3, 3), gy.double(), stride=1, padding=1).float()
+    xb, gb = _nhwc(x).to(DEV).bfloat16(), _nhwc(gy).to(DEV).bfloat16()
+    slabs = torch.full((256, 64, 576), float("nan"), device=DEV)
+    ns = lib.xr_conv64_wgrad(ptr(xb), ptr(gb), ptr(slabs), N, H, W, 256, None, None, None, stream())
+    assert 1 <= ns <= 256
+    dw = _unpack(slabs, ns)
+    split = min(64, (N * H * W + 63) // 64)
+    slabs2 = torch.empty(split, 64, 576, device=DEV)
+    ns2 = lib.xr_conv_wgrad(0, ptr(xb), ptr(gb), ptr(slabs2), N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, split, stream())
+    dw2 = _unpack(slabs2, ns2)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()
+    assert rel(dw, ref) < 2e-5, rel(dw, ref)          # exact bf16 products, fp32 accumulation
+    assert rel(dw, dw2) < 2e-5, rel(dw, dw2)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16), (3, 24, 40), (2, 112, 112), (300, 8, 8)])
+@pytest.mark.parametrize("with_alpha", [True, False])
+def test_direct_wgrad64_transform_on_load(case, with_alpha):
+    """in_scale / in_shift / in_alpha: the weight gradient against x' = prelu(x * scale[n] + shift[n], alpha) rounded to bf16,
+    the activation the forward's on-load transform fed to the MFMAs (never written to HBM)."""
+    from xrface._lib import lib, ptr, stream
+    N, H, W = case
+    x = rnd(f"wgx64x{case}", N, 64, H, W).bfloat16().float()
+    gy = rnd(f"wgx64g{case}", N, 64, H, W).bfloat16().float()
+    sc = (rnd(f"wgx64s{case}", N, 64).abs() + 0.5)
+    sf = rnd(f"wgx64h{case}", N, 64)
+    al = rnd(f"wgx64a{case}", 64).abs() * 0.3
+    xt = x * sc[:, :, None, None] + sf[:, :, None, None]
+    if with_alpha:
+        xt = torch.where(xt > 0, xt, xt * al[None, :, None, None])
+    xt = xt.bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(xt.double(), (64, 64, 3, 3), gy.double(), stride=1, padding=1).float()
+    xb, gb = _nhwc(x).to(DEV).bfloat16(), _nhwc(gy).to(DEV).bfloat16()
+    scd, sfd, ald = sc.to(DEV), sf.to(DEV), al.to(DEV)
+    slabs = torch.empty(256, 64, 576, device=DEV)
+    ns = lib.xr_conv64_wgrad(ptr(xb), ptr(gb), ptr(slabs), N, H, W, 256, ptr(scd), ptr(sfd), ptr(ald) if with_alpha else None, stream())
+    dw = _unpack(slabs, ns)
+    torch.cuda.synchronize()
+    # the GPU evaluates x * scale + shift as one fused multiply-add: a last-bit difference before the bf16 rounding flips a few
+    # of the 2.4e5 .. 2.5e7 rounded activations by one bf16 ulp
+    assert rel(dw, ref) < 2e-3, rel(dw, ref)
+
+
+def test_direct_wgrad64_argument_checks():
+    from xrface._lib import lib, ptr, stream
+    x = torch.zeros(1, 12, 12, 64, device=DEV, dtype=torch.bfloat16)
+    slabs = torch.empty(4, 64, 576, device=DEV)
+    with pytest.raises(RuntimeError):
+        lib.xr_conv64_wgrad(ptr(x), ptr(x), ptr(slabs), 1, 12, 12, 4, None, None, None, stream())      # W % 8 != 0
+    xs = torch.zeros(1, 8, 8, 64, device=DEV, dtype=torch.bfloat16)
+    sc = torch.zeros(1, 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        lib.xr_conv64_wgrad(ptr(xs), ptr(xs), ptr(slabs), 1, 8, 8, 4, ptr(sc), None, None, stream())   # scale without shift
+    with pytest.raises(RuntimeError):
+        lib.xr_conv64_wgrad(ptr(xs), ptr(xs), ptr(slabs), 1, 8, 8, 0, None, None, None, stream())      # no slab capacity
+    ns = lib.xr_conv64_wgrad(ptr(xs), ptr(xs), ptr(slabs), 1, 8, 8, 4, None, None, None, stream())     # capacity caps the grid
+    assert ns == 4
