@@ -598,6 +598,96 @@ __global__ __launch_bounds__(NT) void roc_hist_kernel(const float* __restrict__ 
   }
 }
 
+
+// K-fold ROC sweep over the histogram of roc_hist_kernel (utils/utils.py:51-83), ONE workgroup: hist[f][lab][j] is turned into
+// prefix sums in place (cum[f][lab][t] = #{pairs of the fold's test split predicted same at threshold t}), then per fold the
+// threshold maximising the TRAIN-split accuracy (first maximum, as numpy.argmax; the accuracy's denominator is the same for
+// every threshold, so the integer numerator tp + tn decides -- exact), the test accuracy at it, and tpr / fpr at every
+// threshold; the fold means are summed in fold order and divided by F like numpy.mean(axis=0).  All rates are IEEE double
+// divisions of the same integers the host formula divides: bit-identical to the numpy evaluation.
+constexpr int RT = 1024;
+__global__ __launch_bounds__(RT) void roc_sweep_kernel(unsigned long long* __restrict__ hist, int T, int F, double* __restrict__ mean_tpr,
+                                                       double* __restrict__ mean_fpr, double* __restrict__ acc,
+                                                       int* __restrict__ best_idx) {
+  __shared__ long long s_part[RT];
+  __shared__ long long s_tot[64];     // [f][lab], F <= 32
+  __shared__ long long s_bv[RT / 64];
+  __shared__ int s_bi[RT / 64];
+  __shared__ int s_best;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int nb = T + 1, seg = (nb + RT - 1) / RT;
+  const int j0 = t * seg, j1 = (j0 + seg < nb) ? j0 + seg : nb;
+  // ---- in-place inclusive prefix sums of the 2 F rows
+  for (int row = 0; row < 2 * F; ++row) {
+    unsigned long long* h = hist + (size_t)row * nb;
+    long long sum = 0;
+    for (int j = j0; j < j1; ++j) sum += (long long)h[j];
+    s_part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < RT; off <<= 1) {       // Hillis-Steele inclusive scan of the segment sums
+      const long long v = t >= off ? s_part[t - off] : 0;
+      __syncthreads();
+      s_part[t] += v;
+      __syncthreads();
+    }
+    long long run = s_part[t] - sum;               // exclusive base of this thread's segment
+    for (int j = j0; j < j1; ++j) {
+      run += (long long)h[j];
+      h[j] = (unsigned long long)run;
+    }
+    if (t == RT - 1) s_tot[row] = s_part[t];
+    __syncthreads();
+  }
+  long long pos_all = 0, neg_all = 0;
+  for (int f = 0; f < F; ++f) { neg_all += s_tot[2 * f]; pos_all += s_tot[2 * f + 1]; }
+  // ---- per fold: arg max over thresholds of the train-split (tp + tn); ties -> smallest index
+  for (int f = 0; f < F; ++f) {
+    const long long neg_tr = neg_all - s_tot[2 * f];
+    long long bv = -1;
+    int bi = 0x7fffffff;
+    for (int th = t; th < T; th += RT) {
+      long long tp_all = 0, fp_all = 0;
+      for (int g = 0; g < F; ++g) {
+        fp_all += (long long)hist[(size_t)(2 * g) * nb + th];
+        tp_all += (long long)hist[(size_t)(2 * g + 1) * nb + th];
+      }
+      const long long tp_tr = tp_all - (long long)hist[(size_t)(2 * f + 1) * nb + th];
+      const long long fp_tr = fp_all - (long long)hist[(size_t)(2 * f) * nb + th];
+      const long long v = tp_tr + (neg_tr - fp_tr);
+      if (v > bv) { bv = v; bi = th; }             // th ascending per thread: keeps the first maximum
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { s_bv[wv] = bv; s_bi[wv] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < RT / 64; ++w)
+        if (s_bv[w] > bv || (s_bv[w] == bv && s_bi[w] < bi)) { bv = s_bv[w]; bi = s_bi[w]; }
+      s_best = bi;
+      best_idx[f] = bi;
+      const long long tp = (long long)hist[(size_t)(2 * f + 1) * nb + bi], fp = (long long)hist[(size_t)(2 * f) * nb + bi];
+      const long long tn = s_tot[2 * f] - fp, n_te = s_tot[2 * f] + s_tot[2 * f + 1];
+      acc[f] = (double)(tp + tn) / (double)n_te;   // n_te == 0 -> nan, as the host formula
+    }
+    __syncthreads();
+  }
+  // ---- tpr / fpr at every threshold, mean over folds (fold order)
+  for (int th = t; th < T; th += RT) {
+    double st = 0.0, sf = 0.0;
+    for (int f = 0; f < F; ++f) {
+      const long long tp = (long long)hist[(size_t)(2 * f + 1) * nb + th], fp = (long long)hist[(size_t)(2 * f) * nb + th];
+      const long long pos = s_tot[2 * f + 1], neg = s_tot[2 * f];
+      st += pos == 0 ? 0.0 : (double)tp / (double)pos;
+      sf += neg == 0 ? 0.0 : (double)fp / (double)neg;
+    }
+    mean_tpr[th] = st / (double)F;
+    mean_fpr[th] = sf / (double)F;
+  }
+}
+
 }  // namespace
 
 #define XR_DISPATCH(dtype, ...)                 \
@@ -878,5 +968,13 @@ extern "C" int xr_roc_hist(const float* dist, const uint8_t* issame, const int32
   hipLaunchKernelGGL(roc_hist_kernel, dim3(grid_for(P, NT, 2048)), dim3(NT), (size_t)T * sizeof(float), (hipStream_t)stream, dist,
                      issame, fold_id, thresholds, hist, P, T, F);
   XR_CHECK_LAUNCH("xr_roc_hist");
+  return XR_OK;
+}
+extern "C" int xr_roc_sweep(unsigned long long* hist, int T, int F, double* mean_tpr, double* mean_fpr, double* acc, int* best_idx,
+                            void* stream) {
+  XR_CHECK_ARG(hist && mean_tpr && mean_fpr && acc && best_idx, "xr_roc_sweep: null pointer");
+  XR_CHECK_ARG(T > 0 && T <= 16000 && F >= 2 && F <= 32, "xr_roc_sweep: needs 0 < T <= 16000 thresholds and 2 <= F <= 32 folds");
+  hipLaunchKernelGGL(roc_sweep_kernel, dim3(1), dim3(RT), 0, (hipStream_t)stream, hist, T, F, mean_tpr, mean_fpr, acc, best_idx);
+  XR_CHECK_LAUNCH("xr_roc_sweep");
   return XR_OK;
 }

@@ -22,7 +22,7 @@ ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 _CT = {
     "int": ctypes.c_int, "float": ctypes.c_float, "int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64,
-    "size_t": ctypes.c_size_t,
+    "size_t": ctypes.c_size_t, "double": ctypes.c_double,
 }
 
 

@@ -68,34 +68,31 @@ def calculate_roc(thresholds, embeddings1, embeddings2, actual_issame, nrof_fold
     assert np.all(np.diff(thresholds) > 0), "thresholds must be ascending"
     issame = np.asarray(actual_issame).astype(bool)
     nrof_pairs = min(len(issame), embeddings1.shape[0])
+    if nrof_folds < 2:
+        # the reference builds KFold(n_splits=nrof_folds) (utils/utils.py:31), which rejects a single fold: there is no train split
+        raise ValueError("k-fold cross-validation requires at least one train/test split by setting nrof_folds=2 or more, "
+                         f"got nrof_folds={nrof_folds}.")
     if fold_id is None:
         from sklearn.model_selection import KFold
         fold_id = np.empty(nrof_pairs, dtype=np.int32)
         for f, (_, test_set) in enumerate(KFold(n_splits=nrof_folds, shuffle=True).split(np.arange(nrof_pairs))):
             fold_id[test_set] = f
     dist = pair_dist(embeddings1[:nrof_pairs], embeddings2[:nrof_pairs])
-    hist = roc_histograms(dist, issame[:nrof_pairs], fold_id, thresholds, nrof_folds).cpu().numpy()
-    # predicted-same at threshold t  <=>  j <= t  ->  prefix sums over j give tp/fp per fold (test split)
-    cum = np.cumsum(hist, axis=2)[:, :, :-1]            # [F][2][T]
-    tot = hist.sum(axis=2)                               # [F][2]
-    tp_te, fp_te = cum[:, 1, :], cum[:, 0, :]
-    fn_te, tn_te = tot[:, 1, None] - tp_te, tot[:, 0, None] - fp_te
-    tp_all, fp_all = tp_te.sum(0), fp_te.sum(0)
-    pos_all, neg_all = tot[:, 1].sum(), tot[:, 0].sum()
-    nth = len(thresholds)
-    tprs, fprs = np.zeros((nrof_folds, nth)), np.zeros((nrof_folds, nth))
-    accuracy, best_thresholds = np.zeros(nrof_folds), np.zeros(nrof_folds)
-    for f in range(nrof_folds):
-        tp_tr, fp_tr = tp_all - tp_te[f], fp_all - fp_te[f]
-        pos_tr, neg_tr = pos_all - tot[f, 1], neg_all - tot[f, 0]
-        n_tr = pos_tr + neg_tr
-        acc_train = (tp_tr + (neg_tr - fp_tr)).astype(np.float64) / float(n_tr)
-        bi = int(np.argmax(acc_train))
-        best_thresholds[f] = thresholds[bi]
-        n_te = int(tot[f].sum())
-        tprs[f], fprs[f], acc_te = _rates(tp_te[f], fp_te[f], tn_te[f], fn_te[f], n_te)
-        accuracy[f] = acc_te[bi]
-    return np.mean(tprs, 0), np.mean(fprs, 0), accuracy.mean(), best_thresholds
+    hist = roc_histograms(dist, issame[:nrof_pairs], fold_id, thresholds, nrof_folds)
+    tpr, fpr, acc, best = roc_sweep(hist, len(thresholds), nrof_folds)
+    return tpr, fpr, acc.mean(), thresholds[best].astype(np.float64)
+
+
+def roc_sweep(hist, T, nrof_folds):
+    """The K-fold sweep of utils/utils.py:51-83 on the device (xr_roc_sweep, one workgroup) over the int64 histogram [F][2][T+1]
+    (overwritten with its prefix sums): (mean tpr [T], mean fpr [T], per-fold accuracy [F], per-fold best threshold index [F]).
+    Integer confusion counts, fp64 rates: bit-identical to the numpy evaluation (oracle/cpu_ref.py:calculate_roc)."""
+    dev = hist.device
+    out = torch.empty(2 * T + nrof_folds, dtype=torch.float64, device=dev)
+    best = torch.empty(nrof_folds, dtype=torch.int32, device=dev)
+    lib.xr_roc_sweep(ptr(hist), T, nrof_folds, ptr(out), ptr(out[T:]), ptr(out[2 * T:]), ptr(best), stream())
+    res = out.cpu().numpy()
+    return res[:T], res[T:2 * T], res[2 * T:], best.cpu().numpy().astype(np.int64)
 
 
 class AverageMeter(object):

@@ -313,6 +313,23 @@ int xr_pairdist_l2(const float* e1, const float* e2, float* dist, int64_t P, int
  * thresholds ascending fp32 [T]; fold_id int32 [P] (values < F); hist int64 [F][2][T+1], caller zeroes. */
 int xr_roc_hist(const float* dist, const uint8_t* issame, const int32_t* fold_id, const float* thresholds,
                 unsigned long long* hist, int64_t P, int T, int F, void* stream);
+/* K-fold sweep over that histogram on the device (utils/utils.py:51-83; one workgroup): hist is overwritten with its prefix
+ * sums over j; per fold f the threshold index maximising the accuracy of the OTHER folds (first maximum, numpy.argmax) ->
+ * best_idx[f], the fold's own accuracy at it -> acc[f] (fp64); mean over folds of tpr / fpr at every threshold -> mean_tpr[T],
+ * mean_fpr[T] (fp64; bit-identical to the numpy evaluation of the same integer counts).  2 <= F <= 32. */
+int xr_roc_sweep(unsigned long long* hist, int T, int F, double* mean_tpr, double* mean_fpr, double* acc, int* best_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Loader-side tensor synthesis on the device (SUPER_RESOLUTION/FHN_loader.py:65-66,119-137,
+ * helen_loader.py:124-143).
+ * xr_lr_synth: hr uint8 [N][H][W][3] (the PIL crop) -> Image.resize((low[n], low[n])).resize((W, H), BICUBIC), Pillow's 8-bit
+ * resampler restated (bit-identical to PIL), as uint8 [N][H][W][3] (lr_u8, optional) and / or after ToTensor + Normalize(0.5, 0.5)
+ * as float32 [N][3][H][W] (lr_norm, optional).  low int32 [N] on the device, values in [max(H, W) / 16, max_low] (clamped);
+ * max_low <= min(H, W); one workgroup per image, everything in LDS (H * W * 3 + intermediates <= 160 KiB). */
+int xr_lr_synth(const uint8_t* hr, const int32_t* low, int max_low, uint8_t* lr_u8, float* lr_norm, int N, int H, int W, void* stream);
+/* xr_heatmap: hm[n][y][x] = sum_i exp(-((x - l[n][i][0])^2 + (y - l[n][i][1])^2) / (2 sigma^2)), landmarks fp64 [N][L][2] = (x, y);
+ * bumps in fp64, float32 running sum in landmark order (generate_hm / gaussian_k of the reference loaders). */
+int xr_heatmap(const double* landmarks, float* hm, int N, int L, int H, int W, double sigma, void* stream);
 
 #ifdef __cplusplus
 }

@@ -589,3 +589,108 @@ def c4_step_grads(fhn_sds, s_sd, a_sd, t_sd, lr_img, hr_img, taps=IR50_STAGE_END
     outs = dict(sr=sr.detach(), coarse=coarse.detach(), s_emb=s[0].detach(), a_emb=a[0].detach(), t_emb=t[0],
                 s_taps=[v.detach() for v in s[1:]], a_taps=[v.detach() for v in a[1:]], t_taps=list(t[1:]))
     return (s_loss.detach(), a_loss.detach()), outs, grads, (st_s, st_a)
+
+
+# ----------------------------------------------------------------------------- loader-side synthesis
+# SUPER_RESOLUTION/FHN_loader.py:65-66 makes the low-resolution input with Pillow:
+#     lr_img = sr_img.resize((int(128 / scale), int(128 / scale))).resize((112, 112), Image.BICUBIC)
+# (Image.resize defaults to BICUBIC).  Pillow is a third-party dependency of the reference (unpinned there; 12.2.0 in this
+# image); its 8-bit resampler (src/libImaging/Resample.c) is restated below from its published algorithm -- separable
+# convolution with the a = -0.5 cubic, support 2 * max(scale, 1) (antialiasing when shrinking), per-output-pixel windows,
+# coefficients normalised in double then rounded to 22-bit fixed point, the horizontal pass first, each pass rounding to
+# uint8 -- and pinned against PIL itself by oracle/make_golden.py (bit-exact) and the committed tests/golden/loader.npz.
+_PIL_PRECISION_BITS = 32 - 8 - 2
+
+
+def _pil_bicubic(x):
+    a = -0.5
+    x = abs(x)
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_coeffs(in_size, out_size):
+    """(bounds [out][2] = (first input index, tap count), kk [out][ksize] int32 fixed-point taps) of Resample.c:precompute_coeffs
+    + normalize_coeffs_8bpc for the full-image box."""
+    import math
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_pil_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        for x in range(xmax):
+            v = k[x] / ww if ww != 0.0 else k[x]
+            kk[xx, x] = int(-0.5 + v * (1 << _PIL_PRECISION_BITS)) if v < 0 else int(0.5 + v * (1 << _PIL_PRECISION_BITS))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _pil_pass(img, out_size, axis):
+    """One 8-bit resampling pass along ``axis`` (0 = vertical, 1 = horizontal) of a uint8 [H][W][C] image."""
+    src = np.moveaxis(img.astype(np.int64), axis, 0)
+    bounds, kk = pil_coeffs(src.shape[0], out_size)
+    out = np.empty((out_size,) + src.shape[1:], np.int64)
+    for xx in range(out_size):
+        x0, n = bounds[xx]
+        acc = np.full(src.shape[1:], 1 << (_PIL_PRECISION_BITS - 1), np.int64)
+        for x in range(n):
+            acc += src[x0 + x] * int(kk[xx, x])
+        out[xx] = acc >> _PIL_PRECISION_BITS
+    return np.moveaxis(np.clip(out, 0, 255).astype(np.uint8), 0, axis)
+
+
+def pil_resize_bicubic(img, out_w, out_h):
+    """PIL.Image.resize((out_w, out_h), BICUBIC) of a uint8 [H][W][C] image: horizontal pass, then vertical (Resample.c)."""
+    h, w = img.shape[:2]
+    if out_w != w:
+        img = _pil_pass(img, out_w, 1)
+    if out_h != h:
+        img = _pil_pass(img, out_h, 0)
+    return img
+
+
+def lr_from_hr_u8(hr_u8, low):
+    """FHN_loader.py:65-66 on a uint8 [H][W][3] crop: down to low x low, back up to H x W, both bicubic."""
+    h, w = hr_u8.shape[:2]
+    return pil_resize_bicubic(pil_resize_bicubic(hr_u8, low, low), w, h)
+
+
+def to_tensor_normalize(img_u8):
+    """transforms.ToTensor() + Normalize(0.5, 0.5) (FHN_loader.py:30-35): uint8 HWC -> float32 CHW in [-1, 1]."""
+    t = torch.from_numpy(np.ascontiguousarray(img_u8)).permute(2, 0, 1).to(torch.float32).div(255)
+    return (t - 0.5) / 0.5
+
+
+def gaussian_k(x0, y0, sigma, width, height):
+    """FHN_loader.py:131-137 / helen_loader.py:124-130: one Gaussian bump, float64 [height][width]."""
+    x = np.arange(0, width, 1, float)
+    y = np.arange(0, height, 1, float)[:, np.newaxis]
+    return np.exp(-((x - x0) ** 2 + (y - y0) ** 2) / (2 * sigma ** 2))
+
+
+def generate_hm(height, width, landmark, s=2.0):
+    """FHN_loader.py:119-129 / helen_loader.py:132-143: the sum of one Gaussian per landmark (x, y), accumulated into a
+    float32 map (each float64 bump is added to the float32 running sum, as the in-place += of the reference does)."""
+    hm = np.zeros((height, width), dtype=np.float32)
+    for i in range(np.shape(landmark)[0]):
+        hm += gaussian_k(landmark[i][0], landmark[i][1], s, width, height)
+    return hm

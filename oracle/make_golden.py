@@ -446,6 +446,57 @@ def sec_gan(keys, t0):
 SECTIONS = {}   # filled below main's helpers (name -> function), in generation order
 
 
+def _ref_methods(path, names):
+    """The named methods of the reference's Dataset class as plain functions.  The module itself cannot be imported (torchvision /
+    pandas loaders), but these methods are self-contained numpy code: their FunctionDef nodes are compiled unchanged."""
+    import ast
+    tree = ast.parse(open(path).read())
+    fns = [n for c in ast.walk(tree) if isinstance(c, ast.ClassDef) for n in c.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert {f.name for f in fns} == set(names), (path, names)
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, "exec"), ns)
+    return type("RefMethods", (), {n: ns[n] for n in names})()
+
+
+def sec_loader(keys, t0):
+    """low-resolution synthesis (the PIL calls of FHN_loader.py:65-66, run on PIL itself) and heat-maps (the reference's
+    own generate_hm / gaussian_k methods, FHN_loader.py:119-137 and helen_loader.py:124-143)."""
+    import PIL
+    from PIL import Image
+    st = {}
+    rng = np.random.RandomState(7)
+    imgs = [(rng.rand(112, 112, 3) * 255).astype(np.uint8)]
+    for k in (5, 11):   # smooth face-like fields
+        lo = (rng.rand(k, k, 3) * 255).astype(np.uint8)
+        imgs.append(np.array(Image.fromarray(lo).resize((112, 112), Image.BILINEAR)))
+    hr = np.stack(imgs)
+    scales = [8, 4, 2]
+    lr = []
+    for im, sc in zip(hr, scales):
+        sr_img = Image.fromarray(im)
+        lr_img = sr_img.resize((int(128 / sc), int(128 / sc))).resize((112, 112), Image.BICUBIC)   # FHN_loader.py:65-66 verbatim
+        lr.append(np.array(lr_img))
+        assert np.array_equal(lr[-1], R.lr_from_hr_u8(im, int(128 / sc))), "PIL restatement is not bit-exact"
+        for low in (16, 32, 64):
+            assert np.array_equal(np.array(sr_img.resize((low, low)).resize((112, 112), Image.BICUBIC)), R.lr_from_hr_u8(im, low))
+    st["hr_u8"], st["lr_u8"], st["scale"] = hr, np.stack(lr), np.asarray(scales, np.int32)
+    st["pil_version"] = np.asarray([int(v) for v in PIL.__version__.split(".")[:3]], np.int32)
+    fhn = _ref_methods(os.path.join(REF, "SUPER_RESOLUTION", "FHN_loader.py"), ("generate_hm", "gaussian_k"))
+    helen = _ref_methods(os.path.join(REF, "helen_loader.py"), ("generate_hm", "gaussian_k"))
+    lm68 = rng.rand(2, 68, 2) * 130.0 - 9.0        # some landmarks fall outside the 112 x 112 map, as after rotate + crop
+    lm194 = rng.rand(194, 2) * 112.0
+    st["lm68"], st["lm194"] = lm68, lm194
+    st["hm68"] = np.stack([fhn.generate_hm(height=112, width=112, landmark=l, s=2.0) for l in lm68])
+    st["hm194"] = helen.generate_hm(height=112, width=112, landmark=lm194, s=1.3)
+    for l, h in zip(lm68, st["hm68"]):
+        assert np.array_equal(h, R.generate_hm(112, 112, l, 2.0)), "generate_hm restatement differs from the reference"
+    assert np.array_equal(st["hm194"], R.generate_hm(112, 112, lm194, 1.3))
+    assert st["hm68"].dtype == np.float32
+    np.savez_compressed(os.path.join(OUT, "loader.npz"), **st)
+    print(f"[golden] loader: PIL {PIL.__version__} resize chain bit-exact, heat-maps == reference methods  [{time.time() - t0:.1f}s]")
+
+
+
 def main(argv):
     """python oracle/make_golden.py [section ...]   (no argument: every section)"""
     torch.manual_seed(0)
@@ -466,7 +517,7 @@ def main(argv):
 
 
 SECTIONS.update(fsrnet_root=sec_fsrnet_root, fsrnet_sr=sec_fsrnet_sr, irse=sec_irse, resnet_kd=sec_resnet_kd,
-                losses_roc=sec_losses_roc, c4=sec_c4, gan=sec_gan)
+                losses_roc=sec_losses_roc, c4=sec_c4, gan=sec_gan, loader=sec_loader)
 
 if __name__ == "__main__":
     main(sys.argv[1:])

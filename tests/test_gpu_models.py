@@ -25,6 +25,17 @@ TOL = 1e-3       # forward outputs: SR images, heat-maps, embeddings, losses (no
 # (3e-2 for the 2 x ResNet-34 + IR-50 KD chain); forward outputs and losses are held to the north-star 1e-3.
 GRAD_TOL = 1e-2
 KD_GRAD_TOL = 3e-2
+# These flat caps are justified, not assumed: tests/golden/grad_spread.json (oracle/grad_conditioning.py, CPU only) holds the
+# CPU oracle's OWN fp32-vs-fp64 error of the same gradients on the same inputs -- the distance of the fp32 fixtures from the exact
+# answer.  spread_tol() bounds the HIP path's error by min(flat cap, K_SPREAD x the oracle's worst-tensor error): an fp32
+# implementation is not asked to sit closer to the fixture than the fixture sits to the truth, and never gets more than the cap.
+K_SPREAD = 2.0
+with open(os.path.join(GOLD, "grad_spread.json")) as _f:
+    GRAD_SPREAD = json.load(_f)
+
+
+def spread_tol(case, net, cap):
+    return min(cap, K_SPREAD * GRAD_SPREAD[case][net]["worst"])
 
 
 def load_det(module, seed=0):
@@ -203,7 +214,7 @@ def test_resnet34_and_kd_step():
             pre = f"kd/{who}/grad/"
             if key.startswith(pre):
                 name = key[len(pre):].replace("@digest", "")
-                check_against(st, pre + name, g[name], KD_GRAD_TOL, floor=grad_floor(st, pre))
+                check_against(st, pre + name, g[name], spread_tol("kd", who, KD_GRAD_TOL), floor=grad_floor(st, pre))
 
 
 def test_bf16_throughput_mode_embedding_error_is_reported():
@@ -224,7 +235,9 @@ def test_bf16_throughput_mode_embedding_error_is_reported():
     ref = torch.from_numpy(st["irse50/eval/emb"])
     err = float((emb.cpu() - ref).norm(dim=1).max() / ref.norm(dim=1).min())
     print(f"[bf16] IR-SE-50 embedding relative L2 error vs fp32 reference: {err:.3e}")
-    assert err < 0.1
+    # measured 7.3e-3 (bf16 operands, 8 significand bits, through 50 convolutions); bench.py reports the same quantity for the mode
+    # it times (embedding_rel_l2_vs_cpu).  1.5 x the measurement, not an order of magnitude
+    assert err < 1.1e-2
 
 
 def test_c2_full_size_bf16_step_tracks_fp32_parity_mode():
@@ -372,29 +385,43 @@ def test_fhn_perceptual_step_matches_oracle():
     assert rel_err(outs["coarse"], o_ref["coarse"]) < TOL and rel_err(outs["sr"], o_ref["sr"]) < TOL
     for k in ("coarse", "prior", "encdec"):
         assert abs(losses[k].item() - l_ref[k].item()) <= 2 * TOL * abs(l_ref[k].item()), (k, losses[k].item(), l_ref[k].item())
+    # The gradients of this step are ill-conditioned in fp32 (IR-50 + generator chains; the prior is 4 x depth-4 bottleneck
+    # hourglasses: 475 convs, InstanceNorm over as few as 7 x 7 samples, ReLU / max-pool kinks).  So the experiment is run three
+    # ways on the same weights and inputs -- CPU oracle fp64 (the reference point), CPU oracle fp32 (what the reference computes),
+    # HIP fp32 mode -- and the HIP path's distance from the fp64 gradients is bounded by a multiple of the fp32 oracle's own
+    # distance from them (per tensor, normalised like check_against; and for the whole gradient direction).
+    to64 = lambda sd: {k_: (v.double() if v.dtype.is_floating_point else v) for k_, v in sd.items()}
+    _, _, g64 = R.fhn_perceptual_grads({k: to64(v) for k, v in sds.items()}, to64(bb_sd), lr.double(), hr.double(), hm.double(), par)
+    K_T, K_COS = 4.0, 16.0     # per-tensor error factor; (1 - cosine) is quadratic in the error, hence the square
     for k in ("coarse", "prior", "encoder", "decoder"):
         got = dict(nets[k].named_parameters())
-        scale = max(float(v.abs().max()) for v in g_ref[k].values() if v is not None)
-        worst = 0.0
+        names = [n for n, g_ in g64[k].items() if g_ is not None]
         for name, gr in g_ref[k].items():
-            if gr is None:
-                assert got[name].grad is None, (k, name)
-                continue
-            err = float((got[name].grad.cpu().double() - gr.double()).abs().max()) / max(float(gr.abs().max()), 1e-2 * scale)
-            if err > worst:
-                worst, wname = err, name
-        if k != "prior":
-            assert worst < 6e-2, (k, wname, worst)   # fp32 rounding noise through IR-50 + generator chains (measured 1e-2..3e-2)
-            continue
-        # The 4 x depth-4 bottleneck hourglass (475 convs, InstanceNorm over as few as 7x7 samples, ReLU/max-pool kinks)
-        # is ill-conditioned in fp32: the CPU oracle's own fp32-vs-fp64 gradient spread through ONE such hourglass is
-        # 3e-2 (tools/debug_hg.py).  Per-tensor max-error is meaningless here; require the whole gradient direction
-        # to agree instead.
-        a = torch.cat([got[n].grad.cpu().double().flatten() for n, g_ in g_ref[k].items() if g_ is not None])
-        b = torch.cat([g_.double().flatten() for g_ in g_ref[k].values() if g_ is not None])
-        cos = float((a @ b) / (a.norm() * b.norm()))
-        print(f"[prior] gradient cosine similarity vs oracle: {cos:.5f} (worst tensor {wname}: {worst:.2e})")
-        assert cos > 0.98, cos
+            assert (gr is None) == (got[name].grad is None), (k, name)
+        scale = max(float(g64[k][n].abs().max()) for n in names)
+
+        def worst_of(grads):
+            w, wn = 0.0, None
+            for n in names:
+                den = max(float(g64[k][n].abs().max()), 1e-2 * scale)
+                e = float((grads[n].double().cpu() - g64[k][n]).abs().max()) / den
+                if e > w:
+                    w, wn = e, n
+            return w, wn
+
+        def cos_of(grads):
+            a = torch.cat([grads[n].double().cpu().flatten() for n in names])
+            b = torch.cat([g64[k][n].flatten() for n in names])
+            return float((a @ b) / (a.norm() * b.norm()))
+
+        hip = {n: got[n].grad for n in names}
+        w_hip, wn_hip = worst_of(hip)
+        w_o32, wn_o32 = worst_of(g_ref[k])
+        c_hip, c_o32 = cos_of(hip), cos_of(g_ref[k])
+        print(f"[perceptual/{k}] vs fp64 oracle: HIP fp32 worst {w_hip:.2e} ({wn_hip}), CPU fp32 worst {w_o32:.2e} ({wn_o32}); "
+              f"1 - cosine: HIP {1 - c_hip:.2e}, CPU fp32 {1 - c_o32:.2e}")
+        assert w_hip <= max(K_T * w_o32, 2e-3), (k, wn_hip, w_hip, w_o32)
+        assert 1.0 - c_hip <= max(K_COS * (1.0 - c_o32), 1e-6), (k, c_hip, c_o32)
 
 
 # ---------------------------------------------------------------------------------------------------------------- C4
@@ -449,10 +476,10 @@ def test_c4_composed_step_matches_reference_fixture():
     for got, key in ((sl, "student_loss"), (al, "assistant_loss")):
         ref = float(st[key])
         assert abs(got.item() - ref) <= TOL * abs(ref), (key, got.item(), ref)
-    _check_prefixed_grads(st, "student/", student, KD_GRAD_TOL)
-    _check_prefixed_grads(st, "assistant/", assistant, KD_GRAD_TOL)
+    _check_prefixed_grads(st, "student/", student, spread_tol("c4", "student", KD_GRAD_TOL))
+    _check_prefixed_grads(st, "assistant/", assistant, spread_tol("c4", "assistant", KD_GRAD_TOL))
     for k in ("coarse", "prior", "encoder", "decoder"):
-        _check_prefixed_grads(st, k + "/", fhn[k], KD_GRAD_TOL)
+        _check_prefixed_grads(st, k + "/", fhn[k], spread_tol("c4", k, KD_GRAD_TOL))
     new_sd = student.state_dict()
     for k in ("input_layer.1.running_mean", "body.23.res_layer.4.running_var"):
         check_against(st, f"student/stats/{k}", new_sd[k], TOL)

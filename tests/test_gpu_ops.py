@@ -511,12 +511,28 @@ def test_pairdist_and_roc_against_reference_fixture():
         sel = st["fold_id"] == f
         tp, fp, tn, fn = R.confusion_at(thresholds, st["dist"][sel], same[sel])
         assert np.array_equal(np.cumsum(hist[f, 1])[:-1], tp) and np.array_equal(np.cumsum(hist[f, 0])[:-1], fp)
+    # the K-fold sweep itself, on the device (xr_roc_sweep), fed with the REFERENCE's dist: every output bit-identical to what
+    # the reference's calculate_roc returned (integer counts, fp64 rates, first-maximum argmax, fold-order means)
+    from xrface.utils.utils import roc_sweep
+    hist_d = roc_histograms(torch.from_numpy(st["dist"]).to(DEV), same, st["fold_id"], thresholds, 10)
+    tpr_x, fpr_x, acc_x, best_x = roc_sweep(hist_d, len(thresholds), 10)
+    assert np.array_equal(tpr_x, st["tpr"]) and np.array_equal(fpr_x, st["fpr"])
+    assert acc_x.mean() == float(st["acc"]) and np.array_equal(thresholds[best_x].astype(np.float64), st["best"])
+    assert np.array_equal(hist_d.cpu().numpy(), np.cumsum(hist, axis=2))        # hist is left as its prefix sums
+    # end to end (distances from the HIP kernel differ from numpy's in the last bits: a few pairs cross a threshold)
     tpr, fpr, acc, best = calculate_roc(thresholds, e1, e2, same, nrof_folds=10, fold_id=st["fold_id"])
     assert np.abs(tpr - st["tpr"]).max() < 5e-3 and np.abs(fpr - st["fpr"]).max() < 5e-3
     assert abs(acc - float(st["acc"])) < 5e-3 and np.abs(best - st["best"]).max() <= 6
-    # empty-ish / ragged edge: one pair, one threshold, one fold
-    t1, f1, a1, b1 = calculate_roc(np.array([1.0]), e1[:1], e2[:1], same[:1], nrof_folds=1, fold_id=np.zeros(1, np.int32))
-    assert t1.shape == (1,) and b1.shape == (1,)
+    # edge cases: a single fold has no train split -- the reference's KFold(n_splits=1) raises ValueError, so does this;
+    # ragged: three pairs, two folds, one threshold, one fold without positives (tpr 0 by the reference's convention)
+    with pytest.raises(ValueError):
+        calculate_roc(np.array([1.0]), e1[:1], e2[:1], same[:1], nrof_folds=1, fold_id=np.zeros(1, np.int32))
+    fid = np.array([0, 1, 1], np.int32)
+    lab = np.array([True, False, False])
+    t1, f1, a1, b1 = calculate_roc(np.array([1.0e9]), e1[:3], e2[:3], lab, nrof_folds=2, fold_id=fid)
+    tr, fr, ar, br = R.calculate_roc(np.array([1.0e9]), e1[:3], e2[:3], lab, [(np.where(fid != f)[0], np.where(fid == f)[0]) for f in range(2)])
+    assert t1.shape == (1,) and b1.shape == (2,)
+    assert np.array_equal(t1, tr) and np.array_equal(f1, fr) and a1 == ar and np.array_equal(b1, br)
 
 
 def test_arcface_head_against_fp64_restatement():
@@ -600,3 +616,42 @@ def test_bn_backward_reduction_fused_into_conv_dgrad(cin, depth, stride, hw, dty
         ops.BnLink.take = orig_take
         ops._cfg["fuse_bn_reduce"] = 1
         xrface.set_compute_dtype(torch.float32)
+
+
+def test_lr_synthesis_and_heatmaps_match_pil_and_reference_fixture():
+    """SURVEY 8f-3 on the device: xr_lr_synth == the PIL calls of FHN_loader.py:65-66 bit for bit (uint8), its normalised output ==
+    ToTensor + Normalize bit for bit (float32); xr_heatmap == the reference's generate_hm to float32 rounding."""
+    from tests.helpers import load_gold
+    from oracle import cpu_ref as R
+    from xrface.utils.loader_ops import gaussian_k, generate_hm, lr_from_hr
+    st = load_gold("loader.npz")
+    hr, lr_ref, scale = st["hr_u8"], st["lr_u8"], st["scale"]
+    lr_u8, lr_n = lr_from_hr(hr, scale=scale)                      # one scale per image, as the loader draws them
+    assert np.array_equal(lr_u8.cpu().numpy(), lr_ref)
+    for i in range(len(hr)):
+        assert torch.equal(lr_n[i].cpu(), R.to_tensor_normalize(lr_ref[i]))
+    # every scale of scale_list on every image, against the restatement (pinned to PIL by the CPU suite)
+    for sc in (2, 4, 8):
+        got, _ = lr_from_hr(hr, scale=sc, normalize=False)
+        for i in range(len(hr)):
+            assert np.array_equal(got[i].cpu().numpy(), R.lr_from_hr_u8(hr[i], 128 // sc)), (sc, i)
+    # ragged: non-square crop, odd sizes, low edge equal to one side (that pass is the identity), single image
+    rng = np.random.RandomState(3)
+    odd = (rng.rand(2, 45, 70, 3) * 255).astype(np.uint8)
+    for low in (45, 17, 5):
+        got, _ = lr_from_hr(odd, scale=128 / low, normalize=False)
+        for i in range(2):
+            assert np.array_equal(got[i].cpu().numpy(), R.lr_from_hr_u8(odd[i], low)), low
+    with pytest.raises(ValueError):
+        lr_from_hr(odd, scale=128 / 4)          # 70 / 4 > 16: beyond the tap tables
+    with pytest.raises(ValueError):
+        lr_from_hr(odd, scale=128 / 46)         # larger than the image
+    # heat-maps: fp64 bumps, float32 running sum in landmark order; exp() of the device library vs numpy's may differ in the last
+    # bit of the double, which can move a float32 sum by one ulp
+    hm = generate_hm(112, 112, st["lm68"], s=2.0).cpu().numpy()
+    assert hm.shape == (2, 112, 112) and np.abs(hm - st["hm68"]).max() <= 2.4e-7 * max(1.0, float(st["hm68"].max()))
+    hm2 = generate_hm(112, 112, st["lm194"], s=1.3).cpu().numpy()
+    assert np.abs(hm2 - st["hm194"]).max() <= 2.4e-7 * max(1.0, float(st["hm194"].max()))
+    print(f"[heatmap] exact elements: {(hm == st['hm68']).mean():.4f} / {(hm2 == st['hm194']).mean():.4f}")
+    g = gaussian_k(30.5, 40.25, 2.0, width=112, height=112).cpu().numpy()
+    assert np.abs(g - R.gaussian_k(30.5, 40.25, 2.0, 112, 112).astype(np.float32)).max() <= 1.2e-7 and abs(g[40, 30] - np.exp(-(0.25 + 0.0625) / 8)) < 1e-6
