@@ -376,11 +376,14 @@ def main():
     # each on the stream it is launched on): the per-site table and the choice of the dominant kernel come from it
     bf = dtype == torch.bfloat16
     table = []
-    if rank == 0 and bf:
-        ops._cfg["probe"] = {"all": {}}
+    if bf:
+        # EVERY rank runs this step (it contains the gradient all-reduce); only rank 0 brackets its launches with events
+        if rank == 0:
+            ops._cfg["probe"] = {"all": {}}
         step(args.warmup)
         torch.cuda.synchronize()
-        table = kernel_table(ops._cfg.pop("probe")["all"], args.batch, 1)
+        if rank == 0:
+            table = kernel_table(ops._cfg.pop("probe")["all"], args.batch, 1)
     if world > 1:
         dist.barrier()
         # replicas must still agree after the warm-up steps (same averaged gradients -> same weights)

@@ -55,7 +55,7 @@ class GraphedStep:
         ops._graph["tick_ref"] = int(self.tick.item()) + 1   # the value the first replay sees
         ops.join_side_stream()   # nothing of the warm-up may still be pending on the weight-gradient stream
         graph = torch.cuda.CUDAGraph()
-        ops._zpool.buf = None
+        ops._zpools.clear()
         ops._graph["capturing"] = True
         try:
             with torch.cuda.graph(graph):
@@ -73,7 +73,7 @@ class GraphedStep:
             raise
         finally:
             ops._graph["capturing"] = False
-            ops._zpool.buf = None   # the slab captured above belongs to the graph's memory pool
+            ops._zpools.clear()   # the slab captured above belongs to the graph's memory pool
         self.graph = graph
 
     def __call__(self, *inputs):

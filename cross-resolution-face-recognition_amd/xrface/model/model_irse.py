@@ -203,6 +203,55 @@ class Backbone(Module):
                     m.bias.data.zero_()
 
 
+_LOCKSTEP = {}
+
+
+def forward_taps_lockstep(nets, xs, taps=(2, 6, 20, 23)):
+    """``[net.forward_taps(x, taps) for net, x in zip(nets, xs)]`` for INDEPENDENT backbones of the same depth (the student and the
+    assistant of the residual-KD step: different weights, the same sequence of layers), advanced block by block in lockstep, each on
+    its own stream.  A training step of one such network is a chain of MFMA-bound convolutions and HBM-bound normalisation passes
+    with nothing to overlap them with; two chains side by side let the convolutions of one run under the elementwise passes of the
+    other.  Because the autograd nodes are created alternately, the backward pass interleaves the same way (every node runs on the
+    stream of its forward).  The caller's stream waits for all of them before the outputs are used; after ``backward()`` it must
+    wait again (``lockstep_join``): a network that receives a detached input hands nothing back to the caller's stream."""
+    dev = xs[0].device
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, len(nets))
+    if key not in _LOCKSTEP:
+        _LOCKSTEP[key] = [torch.cuda.Stream(dev, priority=-1) for _ in nets]
+    streams = _LOCKSTEP[key]
+    depth = len(nets[0].body)
+    assert all(len(n.body) == depth for n in nets), "lockstep needs backbones of equal depth"
+    for s in streams:
+        s.wait_stream(main)
+    taps = tuple(taps)
+    with batched_bn_counters(list(nets)):
+        ys, tapped = [None] * len(nets), [[] for _ in nets]
+        for j, (n, x, s) in enumerate(zip(nets, xs, streams)):
+            with torch.cuda.stream(s):
+                ys[j] = n.f_input(enter(x))
+        for i in range(depth):
+            for j, (n, s) in enumerate(zip(nets, streams)):
+                with torch.cuda.stream(s):
+                    ys[j] = n.body[i].f(ys[j])
+                    if i in taps:
+                        tapped[j].append(ys[j])
+        outs = []
+        for j, (n, s) in enumerate(zip(nets, streams)):
+            with torch.cuda.stream(s):
+                outs.append((leave2d(n.f_output(ys[j])), *[leave(t) for t in tapped[j]]))
+    for s in streams:
+        main.wait_stream(s)
+    return outs
+
+
+def lockstep_join(device, n):
+    """The caller's stream waits for the lockstep streams (call after backward(), before the optimizers read the gradients)."""
+    main = torch.cuda.current_stream(device)
+    for s in _LOCKSTEP.get((device.index, n), ()):
+        main.wait_stream(s)
+
+
 class TeacherWithTaps(Module):
     """Wraps a Backbone so ``model(x)`` returns (emb, t1, t2, t3, t4) as distill_main.py:59 expects."""
 

@@ -79,13 +79,18 @@ class batched_bn_counters:
     of one tiny kernel per layer (54 launches per IR-SE-50 forward), and make the layers skip their own increment."""
 
     def __init__(self, root):
-        mods = getattr(root, "_xr_bn_mods", None)
-        if mods is None:
-            mods = [m for m in root.modules() if isinstance(m, _BNMixin) and m.track_running_stats
-                    and m.num_batches_tracked is not None]
-            root.__dict__["_xr_bn_mods"] = mods
-        self.active = root.training and not _NBT_BATCHED[0] and len(mods) > 0
-        self.mods = mods
+        roots = list(root) if isinstance(root, (list, tuple)) else [root]      # several independent networks: one multi-tensor add
+        self.mods = []
+        training = False
+        for r in roots:
+            mods = getattr(r, "_xr_bn_mods", None)
+            if mods is None:
+                mods = [m for m in r.modules() if isinstance(m, _BNMixin) and m.track_running_stats
+                        and m.num_batches_tracked is not None]
+                r.__dict__["_xr_bn_mods"] = mods
+            self.mods += mods
+            training = training or r.training
+        self.active = training and not _NBT_BATCHED[0] and len(self.mods) > 0
 
     def __enter__(self):
         if self.active:

@@ -17,7 +17,8 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 
 EPS = 1e-5
 import os as _os
-_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1"))}
+_cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
+        "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1"))}
 
 
 def set_compute_dtype(dtype):
@@ -75,15 +76,23 @@ class _ZeroPool:
         return v
 
 
-_zpool = _ZeroPool()
+_zpools = {}     # one pool per stream: a slab is zeroed by a memset on the stream that carves from it
 
 # HIP-graph capture state (xrface.graph.GraphedStep): while a step is being captured, the zero slab is re-created inside the
 # capture (so every replay re-zeroes it) and dropout reads a device-side step counter that the graph itself increments
 _graph = {"capturing": False, "tick": None, "tick_ref": 0}
 
 
+def _zpool_of(device):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    zp = _zpools.get(key)
+    if zp is None:
+        zp = _zpools[key] = _ZeroPool()
+    return zp
+
+
 def zeros_f32(shape, device):
-    return _zpool.get(tuple(shape) if not isinstance(shape, int) else (shape,), device)
+    return _zpool_of(device).get(tuple(shape) if not isinstance(shape, int) else (shape,), device)
 
 
 # steps._pair_grads asks autograd for d loss_k / d theta_k only, but ``needs_input_grad`` of the custom Functions was fixed at

@@ -222,19 +222,30 @@ def c4_step(fhn, student, assistant, teacher, lr_img, hr_img, optimizers=None, t
     student.train()
     assistant.train()
     _zero_grads([*fhn.values(), student, assistant], optimizers)
+    lock = (ops._cfg["lockstep"] and hr_img.is_cuda and not ops._graph["capturing"] and hasattr(student, "body")
+            and hasattr(assistant, "body") and len(student.body) == len(assistant.body))
+    # (the frozen teacher's forward stays on the caller's stream: run beside the FHN forward on a third stream it cost +25 % --
+    # its 160 KB-LDS tiles and the persistent one-workgroup-per-CU direct kernels evict each other from the CUs)
     with torch.no_grad():
         t = teacher.forward_taps(hr_img, taps)
     _, coarse = fhn["coarse"](lr_img)
     pf, _, _ = fhn["prior"](coarse)
     ef = fhn["encoder"](coarse)
     sr = fhn["decoder"](torch.cat((pf, ef), 1))
-    s = student.forward_taps(sr, taps)
-    a = assistant.forward_taps(sr.detach(), taps)
+    if lock:
+        # student and assistant are independent given sr: both advance in lockstep on their own streams (model_irse.py)
+        from .model.model_irse import forward_taps_lockstep, lockstep_join
+        s, a = forward_taps_lockstep((student, assistant), (sr, sr.detach()), taps)
+    else:
+        s = student.forward_taps(sr, taps)
+        a = assistant.forward_taps(sr.detach(), taps)
     s_loss = crit(s[0], t[0])
     a_loss = crit((t[0] - s[0]).detach(), a[0])
     for k in range(1, 5):
         a_loss = a_loss + crit(ops.sub_detached(t[k], s[k]), a[k])
     (s_loss + a_loss).backward()
+    if lock:
+        lockstep_join(sr.device, 2)
     if optimizers is not None:
         for o in (optimizers.values() if isinstance(optimizers, dict) else optimizers):
             o.step()

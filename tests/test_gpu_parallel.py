@@ -119,3 +119,26 @@ def test_two_ranks_on_one_gpu_stay_bit_identical():
                 assert e == sorted(e), (tag, e)
     # BatchNorm statistics are per GPU (the reference has no SyncBN): the ranks saw different data, so they must differ
     assert not np.array_equal(got[0]["irse"][3], got[1]["irse"][3])
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_rank_rehearsal_prints_one_line():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed on ONE card over gloo
+    (XR_REHEARSE=1): every rank must take part in every step that contains the gradient all-reduce -- the probe step included --
+    or the job hangs; rank 0 prints exactly one JSON line with the whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XR_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=540, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    assert "cpu_baseline" not in line and "secondary" not in line      # rank-0-at-N=1 legs only
