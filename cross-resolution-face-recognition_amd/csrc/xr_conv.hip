@@ -1211,21 +1211,39 @@ __global__ __launch_bounds__(256) void pack_fwdform_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void unpack_fwdform_kernel(const float* __restrict__ packed, float* __restrict__ dst, int taps,
                                                              int B, int Bp, int Kg, int accumulate, int nslices,
-                                                             int64_t slice_stride) {
+                                                             int64_t slice_stride, int spg) {
+  // block = (row a, 64 consecutive b, slice group z): the group's slices are summed with four independent loads in flight
+  // (coalesced 256-B rows of the packed layout), transposed through LDS, and leave as one contiguous run of 64 * taps floats
+  // of the parameter layout.  With more than one slice group the groups meet in dst by atomicAdd (dst then holds the running
+  // gradient or was zeroed by the launcher).
   extern __shared__ float tile[];
   const int a = blockIdx.y, b0 = blockIdx.x * 64, t = threadIdx.x;
+  const int s_beg = blockIdx.z * spg;
+  const int s_end = (s_beg + spg < nslices) ? s_beg + spg : nslices;
+  const bool atomic = gridDim.z > 1;
   const int nb = (B - b0) < 64 ? (B - b0) : 64;
   for (int e = t; e < 64 * taps; e += 256) {
     const int tp = e >> 6, bl = e & 63;
     if (bl >= nb) continue;
     const float* sp = packed + (int64_t)a * Kg + (int64_t)tp * Bp + b0 + bl;
-    float v = 0.f;
-    for (int sl = 0; sl < nslices; ++sl) v += sp[sl * slice_stride];
-    tile[bl * taps + tp] = v;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int sl = s_beg;
+    for (; sl + 3 < s_end; sl += 4) {
+      v0 += sp[sl * slice_stride];
+      v1 += sp[(sl + 1) * slice_stride];
+      v2 += sp[(sl + 2) * slice_stride];
+      v3 += sp[(sl + 3) * slice_stride];
+    }
+    for (; sl < s_end; ++sl) v0 += sp[sl * slice_stride];
+    tile[bl * taps + tp] = (v0 + v1) + (v2 + v3);
   }
   __syncthreads();
   float* dp = dst + ((int64_t)a * B + b0) * taps;
-  for (int j = t; j < nb * taps; j += 256) dp[j] = accumulate ? dp[j] + tile[j] : tile[j];
+  if (atomic) {
+    for (int j = t; j < nb * taps; j += 256) atomicAdd(dp + j, tile[j]);
+  } else {
+    for (int j = t; j < nb * taps; j += 256) dp[j] = accumulate ? dp[j] + tile[j] : tile[j];
+  }
 }
 
 // (2) parameter [B][A][taps] -> pack [A][tap][Bp]  (the input-gradient pack of a Conv2d: rows = input channel a,
@@ -1470,10 +1488,23 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   XR_CHECK_ARG(packed && dst && nslices >= 1, "xr_unpack_wgrad: null pointer / nslices < 1");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Kg >= taps * Bp, "xr_unpack_wgrad: bad dims");
   const int64_t total = (int64_t)A1 * A2 * taps * B;
-  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 16 && taps <= 64 && A1 <= 65535 && B >= 32) {
-    // wide transposes (Linear viewed as a 7x7 conv: 49 taps): LDS-tiled so both sides stay coalesced
-    hipLaunchKernelGGL(unpack_fwdform_kernel, dim3(cdiv(B, 64), A1), dim3(256), (size_t)64 * taps * sizeof(float),
-                       (hipStream_t)stream, packed, dst, taps, B, Bp, Kg, accumulate & 1, nslices, (int64_t)A1 * Kg);
+  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 2 && taps <= 64 && A1 <= 65535 && B >= 32) {
+    // Conv2d [K][C][R][S] / Linear-as-7x7-conv parameters: the taps are the fastest axis of the parameter and the slowest of
+    // the pack -- LDS-tiled so both sides stay coalesced (a strided read-modify-write of the parameter layout ran at 1.3 TB/s)
+    const int tiles = cdiv(B, 64) * A1;
+    int groups = 1;
+    if (tiles < 1024 && nslices > 8) groups = cdiv(nslices, tiles < 128 ? 8 : 16);   // few output tiles, many slices
+    if (groups > 64) groups = 64;
+    const int spg = cdiv(nslices, groups);
+    groups = cdiv(nslices, spg);
+    if (groups > 1 && !(accumulate & 1)) {
+      if (hipMemsetAsync(dst, 0, (size_t)total * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        xr_set_error("xr_unpack_wgrad: memset failed");
+        return XR_E_LAUNCH;
+      }
+    }
+    hipLaunchKernelGGL(unpack_fwdform_kernel, dim3(cdiv(B, 64), A1, groups), dim3(256), (size_t)64 * taps * sizeof(float),
+                       (hipStream_t)stream, packed, dst, taps, B, Bp, Kg, accumulate & 1, nslices, (int64_t)A1 * Kg, spg);
     XR_CHECK_LAUNCH("xr_unpack_wgrad");
     return XR_OK;
   }

@@ -16,7 +16,8 @@
  *     split into three bf16 planes that together carry all 24 significand bits and the matrix products
  *     run as the six plane-pair MFMAs with fp32 accumulate -- fp32-level accuracy at 6/16 of the
  *     native fp32-MFMA cost);
- *   - stream: hipStream_t passed as void*; work is enqueued on it and never synchronised;
+ *   - stream: hipStream_t passed as void*; work is enqueued on it and never synchronised (one documented exception: xr_pack_plan,
+ *     a set-up call outside the training loop's steady state, waits for its table upload);
  *   - return: 0 on success, negative XR_E_* otherwise; xr_last_error() gives a thread-local
  *     message.  No C++ exception crosses the boundary.  All entry points are re-entrant.
  */
@@ -64,7 +65,10 @@ int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int
  * IR-SE-50); a plan turns them into one launch.  entries: n x 14 int64 host words per parameter
  * {src, dst, nplanes, A1, A2, taps, B, Bp, Kg, sa1, sa2, st, sb, 0} with xr_pack_weight's meaning; xr_pack_plan writes the
  * device table (n * 128 bytes at table_dev), stores the dynamic-LDS size in *smem_out and returns the grid size;
- * xr_pack_run(table_dev, n, blocks, smem) then refreshes all packs from the current parameter values. */
+ * xr_pack_run(table_dev, n, blocks, smem) then refreshes all packs from the current parameter values.
+ * xr_pack_plan uploads the table from a host staging vector and WAITS for that copy on `stream` before returning (the only
+ * entry point that synchronises; it runs once per distinct set of stale packs -- a handful of times per training run -- and the
+ * caller caches the table; xr_pack_run, the per-step call, does not synchronise). */
 int xr_pack_plan(const int64_t* entries, int n, void* table_dev, int* smem_out, void* stream);
 int xr_pack_run(const void* table_dev, int n, int blocks, int smem, void* stream);
 
