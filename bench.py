@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--all-sites", action="store_true", help="report every conv launch site in `kernels`, not the top 8")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -440,7 +441,7 @@ def main():
                 "avg_launch_ms": round(in_ms, 4), "launches_timed_in_step": len(evs), "launches_per_step": dom["launches_per_step"],
                 "isolated_launch_ms": round(iso, 4), "isolated_tflops": round(fl / (iso * 1e-3) / 1e12, 1),
                 "algorithmic_gflop_per_launch": round(fl / 1e9, 2)}
-            line["kernels"] = [{k: v for k, v in r.items() if k != "_tag"} for r in table[:8]]
+            line["kernels"] = [{k: v for k, v in r.items() if k != "_tag"} for r in (table if args.all_sites else table[:8])]
             line["conv_ms_per_step_probed"] = round(sum(r["total_ms_per_step"] for r in table), 2)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], emb_err = cpu_baseline(dev, dtype)

@@ -18,7 +18,7 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 EPS = 1e-5
 import os as _os
 _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
-        "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1"))}
+        "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2"))}
 
 
 def set_compute_dtype(dtype):
@@ -188,6 +188,18 @@ def _wgrad64_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed):
             and x.numel() * 2 < (1 << 31))
 
 
+def _wgrad_rows_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed):
+    """bf16 3x3 / pad 1 / stride 1 or 2 with 64-multiple channel counts and an output at least 14 wide: the row-walking direct
+    weight-gradient kernel (csrc/xr_wgrad_rows.hip)."""
+    mode = _cfg["wgrad_rows"]        # 0 off, 1 every eligible layer, 2 only the layers where it won the in-step A/B (see DESIGN.md)
+    if mode == 2 and not ((stride == 1 and Cp <= 128) or (stride == 2 and Cp == 64)):
+        return False
+    return (mode and x.dtype == torch.bfloat16 and R == 3 and S == 3 and pad == 1 and stride in (1, 2) and not transposed
+            and Cp % 64 == 0 and K % 64 == 0 and dy.shape[-1] == K and H % stride == 0 and W % stride == 0 and Ho == H // stride
+            and Wo == W // stride and 14 <= Wo <= (112 if stride == 1 else 64) and x.numel() * 2 < (1 << 31)
+            and dy.numel() * 2 < (1 << 31))
+
+
 def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, kg, split, A1, A2, taps, B, Bp, sa1, sa2, st, sb,
            xform=None):
     """Weight gradient: sliced implicit GEMM (or, for the 64-channel 3x3 layers, the direct row-walking kernel) into partial
@@ -196,14 +208,19 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
     tgt = _direct(w)
     d64 = _wgrad64_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed)
     assert xform is None or d64, "on-load transform needs the direct 64-channel weight-gradient kernel"
+    rows = (not d64) and _wgrad_rows_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed)
     if d64:
         split = min(256, N * H)
+    elif rows:
+        split = max(1, 256 // ((K // 64) * (Cp // 64)))
 
     def launch(slabs, sh, on=None):
         pe = _probe_begin(("wgrad", Cp, K, H, W, R, stride), on)
         if d64:
             sc, sf, al = xform if xform is not None else (None, None, None)
             ns = lib.xr_conv64_wgrad(ptr(x), ptr(dy), ptr(slabs), N, H, W, split, ptr(sc), ptr(sf), ptr(al), sh)
+        elif rows:
+            ns = lib.xr_conv_wgrad_rows(ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, K, stride, split, sh)
         else:
             ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
                                    kg, split, sh)

@@ -141,6 +141,15 @@ int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, 
  * slabs must hold max_slabs * 64 * 576 floats.  RETURNS the number of slabs written (1 <= value <= max_slabs) or a negative XR_E_*. */
 int xr_conv64_wgrad(const void* in, const void* dy, float* slabs, int N, int H, int W, int max_slabs, const float* in_scale,
                     const float* in_shift, const float* in_alpha, void* stream);
+/* Direct weight gradient of the 3x3 / pad 1 / stride 1 or 2 bf16 convolutions with C % 64 == 0 and K % 64 == 0 (IR / ResNet body
+ * layers, model_irse.py:56-62, model/resnet.py:24-47): the result of xr_conv_wgrad(XR_BF16, ..., R = S = 3, pad 1, ldy = K,
+ * Kg = 9 * C) as `n` partial slabs [n][K][9 * C] in the same packed layout (sum them with xr_unpack_wgrad).  A workgroup owns a
+ * 64 x 64 (k, c) tile and a run of output rows and stages only its 128-byte channel slices of dy [N][H/stride][W/stride][K] and
+ * in [N][H][W][C], each once; stride 2 de-interleaves input columns on the way into LDS.  H, W multiples of the stride; output
+ * width <= 112 (stride 1) / <= 64 (stride 2).  slabs must hold max_slabs * K * 9 * C floats.
+ * RETURNS the number of slabs written (1 <= n <= max_slabs) or a negative XR_E_*. */
+int xr_conv_wgrad_rows(const void* in, const void* dy, float* slabs, int N, int H, int W, int C, int K, int stride, int max_slabs,
+                       void* stream);
 /* Sum the `nslices` slabs and convert to the parameter layout (inverse of xr_pack_weight):
  * dst[a1*sa1 + a2*sa2 + t*st + b*sb] (+)= sum_s packed[s][a][t*Bp + b];  accumulate != 0 adds into dst. */
 int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, int B, int Bp, int Kg,

@@ -262,3 +262,59 @@ def test_direct_wgrad64_argument_checks():
         lib.xr_conv64_wgrad(ptr(xs), ptr(xs), ptr(slabs), 1, 8, 8, 0, None, None, None, stream())      # no slab capacity
     ns = lib.xr_conv64_wgrad(ptr(xs), ptr(xs), ptr(slabs), 1, 8, 8, 4, None, None, None, stream())     # capacity caps the grid
     assert ns == 4
+
+
+# ------------------------------------------------------------------------------------------------ row-walking weight gradient
+ROWS_CASES = [  # N, C, K, H, W, stride
+    (3, 64, 64, 16, 16, 1),      # one chunk per row, RS = 14 rows per step over images of 16 rows
+    (5, 128, 64, 14, 14, 1),     # the 14 x 14 layers: one image per step; two input-channel tiles
+    (2, 64, 192, 28, 28, 1),     # RS = 7, three output-channel tiles
+    (2, 128, 128, 56, 40, 1),    # RS = 3, non-square, 40 columns in a 64-column plan
+    (1, 64, 128, 112, 112, 1),   # RS = 1 (the 112-wide plan), K != C
+    (2, 64, 64, 112, 112, 2),    # stride 2 at the input resolution (model_irse.py:60, first block)
+    (3, 128, 64, 56, 56, 2),     # stride 2, RS = 3
+    (5, 64, 128, 28, 28, 2),     # stride 2, RS = 6 over images of 14 output rows
+    (70, 64, 64, 16, 20, 1),     # more steps than one pass: ragged last step, runs that start mid-image
+    (9, 64, 64, 32, 24, 2),      # stride 2, ragged widths (12 output columns in a 16-column plan)
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES)
+def test_rows_wgrad_matches_fp64_and_the_sliced_kernel(case):
+    """xr_conv_wgrad_rows vs the fp64 CPU weight gradient of the same bf16-rounded operands and vs xr_conv_wgrad (same products)."""
+    from xrface._lib import lib, ptr, stream
+    N, C, K, H, W, s = case
+    Ho, Wo = H // s, W // s
+    x = rnd(f"wgrx{case}", N, C, H, W).bfloat16().float()
+    gy = rnd(f"wgrg{case}", N, K, Ho, Wo).bfloat16().float()
+    ref = torch.nn.grad.conv2d_weight(x.double(), (K, C, 3, 3), gy.double(), stride=s, padding=1).float()
+    xb, gb = _nhwc(x).to(DEV).bfloat16(), _nhwc(gy).to(DEV).bfloat16()
+    kg = 9 * C
+    cap = max(1, 256 // ((K // 64) * (C // 64)))
+    slabs = torch.full((cap, K, kg), float("nan"), device=DEV)
+    ns = lib.xr_conv_wgrad_rows(ptr(xb), ptr(gb), ptr(slabs), N, H, W, C, K, s, cap, stream())
+    assert 1 <= ns <= cap
+    dw = torch.empty(K, C, 3, 3, device=DEV)
+    lib.xr_unpack_wgrad(ptr(slabs), ptr(dw), K, 1, 9, C, C, kg, 9 * C, 0, 1, 9, 0, ns, stream())
+    split = min(32, (N * Ho * Wo + 63) // 64)
+    slabs2 = torch.empty(split, K, kg, device=DEV)
+    ns2 = lib.xr_conv_wgrad(0, ptr(xb), ptr(gb), ptr(slabs2), N, H, W, C, Ho, Wo, K, 3, 3, s, 1, 0, K, kg, split, stream())
+    dw2 = torch.empty(K, C, 3, 3, device=DEV)
+    lib.xr_unpack_wgrad(ptr(slabs2), ptr(dw2), K, 1, 9, C, C, kg, 9 * C, 0, 1, 9, 0, ns2, stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()
+    assert rel(dw, ref) < 2e-5, rel(dw, ref)
+    assert rel(dw, dw2) < 2e-5, rel(dw, dw2)
+
+
+def test_rows_wgrad_argument_checks():
+    from xrface._lib import lib, ptr, stream
+    x = torch.zeros(1, 16, 16, 64, device=DEV, dtype=torch.bfloat16)
+    slabs = torch.empty(2, 64, 576, device=DEV)
+    with pytest.raises(RuntimeError):
+        lib.xr_conv_wgrad_rows(ptr(x), ptr(x), ptr(slabs), 1, 16, 16, 48, 64, 1, 2, stream())     # C % 64
+    with pytest.raises(RuntimeError):
+        lib.xr_conv_wgrad_rows(ptr(x), ptr(x), ptr(slabs), 1, 16, 16, 64, 64, 3, 2, stream())     # stride
+    with pytest.raises(RuntimeError):
+        lib.xr_conv_wgrad_rows(ptr(x), ptr(x), ptr(slabs), 1, 15, 16, 64, 64, 2, 2, stream())     # H % stride
+    assert lib.xr_conv_wgrad_rows(ptr(x), ptr(x), ptr(slabs), 1, 16, 16, 64, 64, 1, 2, stream()) in (1, 2)
