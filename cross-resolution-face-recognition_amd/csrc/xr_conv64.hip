@@ -25,7 +25,10 @@
 //     writes 8-byte packets into an LDS image from which full 128-B pixel rows are streamed out;
 //   * epilogue fusions: bias; per-image sum / sum of squares of the (rounded) output for the InstanceNorm that follows
 //     (accumulated in registers across the tiles of one image, one atomic per channel and image change); residual-gradient
-//     sum (out += ep_add).
+//     sum (out += ep_add); InstanceNorm + PReLU BACKWARD reductions (EP == 3): when the tensor being written is the gradient
+//     dy1 of y1 = prelu(c1 * scale[n] + shift[n]) -- conv2's input gradient in the FSRNet block -- the stream-out also loads the
+//     matching c1 chunk and accumulates sum dz, sum dz * c1 and the PReLU slope term per image and channel, the three sums of
+//     xr_affine_act_bwd_reduce: that pass (two full-tensor reads) disappears.
 #include "xr_common.h"
 #include <type_traits>
 
@@ -63,11 +66,13 @@ struct DC64P {
   const bf16_t* w;        // [64][576] bf16: row = GEMM output channel, column = tap * 64 + reduction channel
   const float* bias;      // [64] or null
   bf16_t* out;
-  const bf16_t* ep_add;   // laid out like out (EP == 2)
+  const bf16_t* ep_add;   // laid out like out: residual gradient (EP == 2) or the norm input c1 (EP == 3)
   const float* n_scale;   // [N][64] per-image affine applied to the input on load (NORM)
   const float* n_shift;
   const float* n_alpha;   // [64] PReLU slope applied after the affine, or null (no activation)
-  float* stats;           // [2][N][64]: sum, sum of squares of the output per image and channel (EP == 1)
+  float* stats;           // [2][N][64]: sum, sum of squares of the output per image and channel (EP == 1);
+                          // [3][N][64]: sum dz, sum dz * c1, sum out * z * [z <= 0] (EP == 3; n_scale / n_shift / n_alpha then
+                          // describe z = c1 * scale + shift, dz = out * prelu'(z) -- the on-load transform is off)
   int N, H, W, tiles_x, tiles_img, ntiles, tpw;
   unsigned io_bytes;      // extent of in / out / ep_add (same shape)
   int dbg;                // tuning knob 14, timing experiments only (results are wrong): bit 0 no halo loads, bit 1 no
@@ -80,7 +85,7 @@ struct TileGeo {          // wave-uniform description of one tile
   bool interior;          // the whole halo lies inside the image
 };
 
-// EP: 0 plain, 1 per-image output statistics, 2 out += ep_add
+// EP: 0 plain, 1 per-image output statistics, 2 out += ep_add, 3 InstanceNorm / PReLU backward reductions of the output
 template <bool TR, bool NORM, int EP>
 __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   constexpr int NPB = 4;   // pixel blocks (32 pixels = 2 image rows x 16 columns) per wave
@@ -119,11 +124,11 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in), 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_add =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 2 ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP >= 2 ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
   float sc[8], sh[8], al[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = 1.f, sh[e] = 0.f, al[e] = 1.f;
-  if (NORM && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
+  if ((NORM || EP == 3) && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
   int n_staged = -1;
 
   auto geo_of = [&](int tl) {
@@ -185,9 +190,9 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   const int oimg = OUTBASE + (t >> 3) * OPITCH + cc * 16;          // + i * RPP * OPITCH
   const int orel0 = ((orow0 * p.W + ocol) * 64 + cc * 8) * 2;      // + i * ORS * W * 128
   const int orstep = ORS * p.W * 128;
-  float bs[8], bss[8];   // EP == 1: statistics of this thread's channel chunk, current image
+  float bs[8], bss[8], b3[8];   // EP == 1 / 3: sums of this thread's channel chunk, current image
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bs[e] = 0.f, bss[e] = 0.f;
+  for (int e = 0; e < 8; ++e) bs[e] = 0.f, bss[e] = 0.f, b3[e] = 0.f;
   int n_stats = -1;
   v4u_t ov[NOUT], addv[NOUT];
   auto out_mask = [&](const TileGeo& g, bool live) {   // bit i: row group i of this thread lies inside the image
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     return ((om >> i) & 1u) ? (unsigned)(base + orel0 + i * orstep) : XR64_OOR;
   };
   auto add_load = [&](int base, unsigned om, int i) {
-    if constexpr (EP == 2) addv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, out_voff(base, om, i), 0, 0);
+    if constexpr (EP >= 2) addv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, out_voff(base, om, i), 0, 0);
   };
   auto out_read = [&](int i) { ov[i] = *reinterpret_cast<const v4u_t*>(smem + oimg + i * RPP * OPITCH); };
   auto out_store = [&](int base, unsigned om, int i) {
@@ -230,6 +235,24 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
         bs[2 * q + 1] += b; bss[2 * q + 1] += b * b;
       }
     }
+    if constexpr (EP == 3) {
+      const bool ok = (om >> i) & 1u;   // rows outside the image: d = 0 (the c1 load returned zeros as well)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned w = ok ? v[q] : 0u, cw = addv[i][q];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          const int e = 2 * q + hlf;
+          const float d = hlf ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+          const float c = hlf ? __uint_as_float(cw & 0xFFFF0000u) : __uint_as_float(cw << 16);
+          const float z = c * sc[e] + sh[e];
+          const float dz = z > 0.f ? d : d * al[e];
+          bs[e] += dz;
+          bss[e] += dz * c;
+          b3[e] += z <= 0.f ? d * z : 0.f;
+        }
+      }
+    }
   };
   auto flush_stats = [&]() {
     // fold the 64 threads that share a chunk column (lanes 8 apart); the 8 waves meet in the atomics (once per image)
@@ -238,18 +261,29 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       float a = bs[e], b = bss[e];
       a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+      float c3 = 0.f;
+      if constexpr (EP == 3) {
+        c3 = b3[e];
+        c3 += __shfl_xor(c3, 8, 64); c3 += __shfl_xor(c3, 16, 64); c3 += __shfl_xor(c3, 32, 64);
+      }
       if (lane < 8 && n_stats >= 0) {
         atomicAdd(p.stats + (size_t)n_stats * 64 + cc * 8 + e, a);
         atomicAdd(p.stats + ((size_t)p.N + n_stats) * 64 + cc * 8 + e, b);
+        if constexpr (EP == 3) atomicAdd(p.stats + ((size_t)2 * p.N + n_stats) * 64 + cc * 8 + e, c3);
       }
       bs[e] = 0.f;
       bss[e] = 0.f;
+      b3[e] = 0.f;
     }
   };
   auto stats_image = [&](int n) {   // wave-uniform: called before the first stream-out item of a tile
-    if (EP == 1 && n != n_stats) {
+    if ((EP == 1 || EP == 3) && n != n_stats) {
       if (n_stats >= 0) flush_stats();
       n_stats = n;
+      if constexpr (EP == 3) {      // coefficients of z = c1 * scale + shift for the image being streamed out
+        ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
+        ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
+      }
     }
   };
   auto norm_image = [&](int n) {    // wave-uniform: per-image transform coefficients of the tile about to be staged
@@ -323,8 +357,8 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       // global loads of tile t+1: slots 1, 4, ..., 31
       if constexpr (k >= 1 && k < 1 + 3 * NCH && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
       // stream-out of tile t-1, row group i: (residual load at 33 + 6 i,) LDS read at RD + ST i, store 3 slots later
-      constexpr int RD = EP == 2 ? 69 : 36, ST = EP == 2 ? 6 : 8;
-      if constexpr (EP == 2 && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
+      constexpr int RD = EP >= 2 ? 69 : 36, ST = EP >= 2 ? 6 : 8;
+      if constexpr (EP >= 2 && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
       if constexpr (k >= RD && k < RD + ST * NOUT && (k - RD) % ST == 0) out_read((k - RD) / ST);
       if constexpr (k >= RD + 3 && k < RD + 3 + ST * NOUT && (k - RD - 3) % ST == 0) out_store(pbase, om, (k - RD - 3) / ST);
       // transform + LDS write of tile t+1 (the loads left >= 55 slots earlier).  NORM: chunk i is transformed two channels
@@ -395,7 +429,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       out_store(prv.base, om, i);
     }
   }
-  if (EP == 1) flush_stats();
+  if (EP == 1 || EP == 3) flush_stats();
 }
 
 template <bool TR, bool NORM, int EP>
@@ -414,12 +448,41 @@ int launch_dconv64(DC64P& p, int grid, hipStream_t st) {
 
 template <bool TR, bool NORM>
 int launch_dconv64_ep(DC64P& p, int grid, hipStream_t st) {
+  if (p.stats != nullptr && p.ep_add != nullptr) {
+    if constexpr (!NORM) return launch_dconv64<TR, false, 3>(p, grid, st);
+    else return XR_E_INVALID;
+  }
   if (p.stats != nullptr) return launch_dconv64<TR, NORM, 1>(p, grid, st);
   if (p.ep_add != nullptr) return launch_dconv64<TR, NORM, 2>(p, grid, st);
   return launch_dconv64<TR, NORM, 0>(p, grid, st);
 }
 
 }  // namespace
+
+static int dconv64_cus() {
+  static std::once_flag once;
+  static int cus = 256;
+  std::call_once(once, [] {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  });
+  return cus;
+}
+
+static int dconv64_run(DC64P& p, int transposed, bool norm, hipStream_t st) {
+  p.tiles_x = cdiv(p.W, TS);
+  p.tiles_img = p.tiles_x * cdiv(p.H, TS);
+  p.ntiles = p.tiles_img * p.N;
+  p.dbg = g_tune[14];
+  // one persistent workgroup per CU; contiguous tile runs (the tiles of an image stay together: halo rows meet in L2 and
+  // the statistics of an image are flushed once)
+  p.tpw = cdiv(p.ntiles, dconv64_cus());
+  const int grid = cdiv(p.ntiles, p.tpw);
+  if (transposed) return norm ? launch_dconv64_ep<true, true>(p, grid, st) : launch_dconv64_ep<true, false>(p, grid, st);
+  return norm ? launch_dconv64_ep<false, true>(p, grid, st) : launch_dconv64_ep<false, false>(p, grid, st);
+}
 
 extern "C" int xr_conv64_direct(const void* in, const void* wpack, const float* bias, void* out, int N, int H, int W,
                                 int transposed, const float* in_scale, const float* in_shift, const float* in_alpha,
@@ -434,24 +497,21 @@ extern "C" int xr_conv64_direct(const void* in, const void* wpack, const float* 
   p.in = (const bf16_t*)in; p.w = (const bf16_t*)wpack; p.bias = bias; p.out = (bf16_t*)out; p.ep_add = (const bf16_t*)ep_add;
   p.n_scale = in_scale; p.n_shift = in_shift; p.n_alpha = in_alpha; p.stats = out_stats;
   p.N = N; p.H = H; p.W = W;
-  p.tiles_x = cdiv(W, TS);
-  p.tiles_img = p.tiles_x * cdiv(H, TS);
-  p.ntiles = p.tiles_img * N;
   p.io_bytes = (unsigned)io_bytes;
-  p.dbg = g_tune[14];
-  int cus = 256;
-  {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
-  // one persistent workgroup per CU; contiguous tile runs (the tiles of an image stay together: halo rows meet in L2 and
-  // the statistics of an image are flushed once)
-  p.tpw = cdiv(p.ntiles, cus);
-  const int grid = cdiv(p.ntiles, p.tpw);
-  hipStream_t st = (hipStream_t)stream;
-  const bool norm = in_scale != nullptr;
-  if (transposed) return norm ? launch_dconv64_ep<true, true>(p, grid, st) : launch_dconv64_ep<true, false>(p, grid, st);
-  return norm ? launch_dconv64_ep<false, true>(p, grid, st) : launch_dconv64_ep<false, false>(p, grid, st);
+  return dconv64_run(p, transposed, in_scale != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int xr_conv64_direct_bwdred(const void* in, const void* wpack, void* out, int N, int H, int W, int transposed,
+                                       const void* red_src, const float* red_scale, const float* red_shift, const float* red_alpha,
+                                       float* red, void* stream) {
+  XR_CHECK_ARG(in && wpack && out && N > 0 && H > 0 && W > 0, "xr_conv64_direct_bwdred: null pointer / non-positive dimension");
+  XR_CHECK_ARG(red_src && red_scale && red_shift && red, "xr_conv64_direct_bwdred: the reduction needs its source, scale, shift and sums");
+  const long long io_bytes = (long long)N * H * W * 64 * 2;
+  XR_CHECK_ARG(io_bytes < (1ll << 31), "xr_conv64_direct_bwdred: tensor larger than 2 GiB");
+  DC64P p{};
+  p.in = (const bf16_t*)in; p.w = (const bf16_t*)wpack; p.out = (bf16_t*)out; p.ep_add = (const bf16_t*)red_src;
+  p.n_scale = red_scale; p.n_shift = red_shift; p.n_alpha = red_alpha; p.stats = red;
+  p.N = N; p.H = H; p.W = W;
+  p.io_bytes = (unsigned)io_bytes;
+  return dconv64_run(p, transposed, false, (hipStream_t)stream);
 }

@@ -222,6 +222,11 @@ def forward_taps_lockstep(nets, xs, taps=(2, 6, 20, 23)):
     streams = _LOCKSTEP[key]
     depth = len(nets[0].body)
     assert all(len(n.body) == depth for n in nets), "lockstep needs backbones of equal depth"
+    # stale weight packs are refreshed by ONE launch for every registered parameter (ops._PackPlan): it must run on the caller's
+    # stream BEFORE the fork -- triggered lazily by the first convolution of one chain it would rewrite the other chain's packs
+    # on a stream the other chain does not wait for
+    if ops._cfg["pack_plan"]:
+        ops._pack_plan.refresh()
     for s in streams:
         s.wait_stream(main)
     taps = tuple(taps)

@@ -18,7 +18,8 @@ from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, 
 EPS = 1e-5
 import os as _os
 _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
-        "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2"))}
+        "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2")),
+        "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1"))}
 
 
 def set_compute_dtype(dtype):
@@ -1136,10 +1137,11 @@ class _ResBlock64(Function):
             t_ = _direct(p_) if has else None
             return t_, ((t_ if t_ is not None else zeros_f32((C,), dev)) if has else None)
 
-        def norm_bwd(xin, scale, shift, res, alf, gmf, mean, invstd, dy, p_g, p_b, p_a, want_res):
-            red = zeros_f32((3, N, C), dev)
-            lib.xr_affine_act_bwd_reduce(d, ptr(xin), ptr(scale), ptr(shift), ptr(res), ptr(alf), ACT_PRELU, ptr(dy), ptr(red), N, HW, C,
-                                         1, stream())
+        def norm_bwd(xin, scale, shift, res, alf, gmf, mean, invstd, dy, p_g, p_b, p_a, want_res, red=None):
+            if red is None:     # (else: the three sums came out of the epilogue of the convolution that produced dy)
+                red = zeros_f32((3, N, C), dev)
+                lib.xr_affine_act_bwd_reduce(d, ptr(xin), ptr(scale), ptr(shift), ptr(res), ptr(alf), ACT_PRELU, ptr(dy), ptr(red), N, HW,
+                                             C, 1, stream())
             coef = torch.empty((3, N, C), **f32)
             (t_g, dg), (t_b, db), (t_a, da) = small(p_g, p_g is not None), small(p_b, p_b is not None), small(p_a, True)
             lib.xr_norm_bwd_coeffs(ptr(red), ptr(gmf), ptr(mean), ptr(invstd), ptr(coef), ptr(dg), ptr(db), ptr(da), N, HW, C, 1, stream())
@@ -1162,7 +1164,19 @@ class _ResBlock64(Function):
         # c2 = conv2(y1), y1 = prelu(IN1(c1))
         tagd = ("dgrad", 64, 64, H, W, 3, 1)
         pkd2, _ = _packed(w2, "dgrad", x.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
-        dy1 = _conv64(dc2, pkd2, torch.empty_like(x), transposed=1, tag=tagd)
+        red1 = None
+        if _cfg["fuse_in_reduce"]:
+            # conv2's input gradient with the reductions of IN1 + PReLU's backward taken in its epilogue (it reads c1 beside the
+            # output it streams out): xr_affine_act_bwd_reduce over (c1, dy1) -- two full-tensor reads -- disappears
+            red1 = zeros_f32((3, N, C), dev)
+            dy1 = torch.empty_like(x)
+            pe = _probe_begin(tagd)
+            lib.xr_conv64_direct_bwdred(ptr(dc2), ptr(pkd2), ptr(dy1), N, H, W, 1, ptr(c1), ptr(scale1), ptr(shift1), ptr(a1f), ptr(red1),
+                                        stream())
+            if pe is not None:
+                pe.record()
+        else:
+            dy1 = _conv64(dc2, pkd2, torch.empty_like(x), transposed=1, tag=tagd)
         dw2 = None
         if ctx.needs_input_grad[5] and _wanted(w2):
             if _wgrad64_ok(c1, dc2, H, W, 64, H, W, 64, 3, 3, 1, 1, 0):
@@ -1174,7 +1188,7 @@ class _ResBlock64(Function):
                 lib.xr_affine_act(d, ptr(c1), ptr(scale1), ptr(shift1), None, ptr(a1f), ACT_PRELU, ptr(y1), N, HW, C, 1, stream())
                 dw2 = _wgrad(w2, y1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64,
                              64, 576, 0, 1, 9)
-        dc1, _, (dg1, db1, da1) = norm_bwd(c1, scale1, shift1, None, a1f, g1f, mean1, invstd1, dy1, g1, b1, a1, False)
+        dc1, _, (dg1, db1, da1) = norm_bwd(c1, scale1, shift1, None, a1f, g1f, mean1, invstd1, dy1, g1, b1, a1, False, red=red1)
         dx = None
         if need_x:
             pkd1, _ = _packed(w1, "dgrad", x.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)

@@ -122,6 +122,16 @@ int xr_conv64_direct(const void* in, const void* wpack, const float* bias, void*
                      const float* in_scale, const float* in_shift, const float* in_alpha, float* out_stats, const void* ep_add,
                      void* stream);
 
+/* The same convolution (no bias, no on-load transform) whose OUTPUT is the gradient dy of y = prelu(c * red_scale[n] + red_shift[n],
+ * red_alpha) -- conv2's input gradient in the FSRNet residual block (model/FSRnet.py:81-85): while the output streams out, the
+ * epilogue loads the matching chunk of c = red_src (laid out like out) and accumulates, per image n and channel,
+ *   red[0][n][ch] += sum dz,  red[1][n][ch] += sum dz * c,  red[2][n][ch] += sum dy * z * [z <= 0],   z = c * scale + shift,
+ *   dz = dy * (z > 0 ? 1 : alpha)   (dy as rounded to bf16; red_alpha NULL: slope 1)
+ * i.e. exactly the three sums of xr_affine_act_bwd_reduce(x = c, dy = out, act = PReLU, G = N): that pass disappears.
+ * red [3][N][64] fp32, zeroed by the caller. */
+int xr_conv64_direct_bwdred(const void* in, const void* wpack, void* out, int N, int H, int W, int transposed, const void* red_src,
+                            const float* red_scale, const float* red_shift, const float* red_alpha, float* red, void* stream);
+
 /* Weight gradient (aten::convolution_backward weight part; same call sites as above).
  * slab[s][k][t*C + c] = sum_{m in slice s} dy[m][k] * gather(in)[m][t][c]   (fp32, PACKED layout [K][Kg])
  * where m runs over the N*Ho*Wo pixels of dy (row pitch ldy), split into `split` contiguous slices, and gather()

@@ -318,3 +318,33 @@ def test_rows_wgrad_argument_checks():
     with pytest.raises(RuntimeError):
         lib.xr_conv_wgrad_rows(ptr(x), ptr(x), ptr(slabs), 1, 15, 16, 64, 64, 2, 2, stream())     # H % stride
     assert lib.xr_conv_wgrad_rows(ptr(x), ptr(x), ptr(slabs), 1, 16, 16, 64, 64, 1, 2, stream()) in (1, 2)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32), (3, 20, 28), (2, 112, 112), (300, 16, 16)])
+@pytest.mark.parametrize("with_alpha", [True, False])
+def test_direct_conv64_backward_reduction_epilogue(case, with_alpha):
+    """xr_conv64_direct_bwdred: same output as the plain input-gradient launch, and its three per-image sums equal those of
+    xr_affine_act_bwd_reduce run over (c1, the bf16 output) -- the pass it replaces."""
+    from xrface import ops
+    from xrface._lib import lib, ptr, stream, ACT_PRELU
+    N, H, W = case
+    HW = H * W
+    g = _nhwc(rnd(f"brg{case}", N, 64, H, W)).to(DEV).bfloat16()
+    c1 = _nhwc(rnd(f"brc{case}", N, 64, H, W)).to(DEV).bfloat16()
+    w = rnd(f"brw{case}", 64, 64, 3, 3, scale=(64 * 9) ** -0.5).to(DEV)
+    sc = (rnd(f"brs{case}", N, 64).abs() + 0.5).to(DEV)
+    sf = rnd(f"brh{case}", N, 64).to(DEV)
+    al = (rnd(f"bra{case}", 64).abs() * 0.3).to(DEV) if with_alpha else torch.ones(64, device=DEV)
+    pkd, _ = ops._packed(w, "dgrad", torch.bfloat16, 64, 1, 9, 64, 64, 9, 0, 1, 576)
+    out0 = torch.empty_like(g)
+    lib.xr_conv64_direct(ptr(g), ptr(pkd), None, ptr(out0), N, H, W, 1, None, None, None, None, None, stream())
+    out = torch.empty_like(g)
+    red = torch.zeros(3, N, 64, device=DEV)
+    lib.xr_conv64_direct_bwdred(ptr(g), ptr(pkd), ptr(out), N, H, W, 1, ptr(c1), ptr(sc), ptr(sf), ptr(al) if with_alpha else None,
+                                ptr(red), stream())
+    ref = torch.zeros(3, N, 64, device=DEV)
+    lib.xr_affine_act_bwd_reduce(0, ptr(c1), ptr(sc), ptr(sf), None, ptr(al), ACT_PRELU, ptr(out0), ptr(ref), N, HW, 64, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out0)
+    for k in range(2 if not with_alpha else 3):        # slope 1: the PReLU slope term is not meaningful
+        assert rel(red[k], ref[k]) < 2e-5, (k, rel(red[k], ref[k]))
