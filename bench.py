@@ -449,7 +449,9 @@ def main():
         if world == 1 and not args.no_secondary and bf:
             del model, flat, opt, reducer
             torch.cuda.empty_cache()
-            line["secondary"] = secondary_workloads(dev)
+            with torch.cuda.stream(hp):      # same stream set-up as the headline: the side work yields to the critical path
+                line["secondary"] = secondary_workloads(dev)
+            torch.cuda.current_stream(dev).wait_stream(hp)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

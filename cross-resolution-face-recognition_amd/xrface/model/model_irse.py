@@ -216,10 +216,13 @@ def forward_taps_lockstep(nets, xs, taps=(2, 6, 20, 23)):
     wait again (``lockstep_join``): a network that receives a detached input hands nothing back to the caller's stream."""
     dev = xs[0].device
     main = torch.cuda.current_stream(dev)
+    # the chains get the CALLER's stream priority: with a higher one, the chain that hands nothing back to the caller (the
+    # assistant) would outrank the work that follows on the caller's stream (the FHN backward) -- measured +10 % on C4
+    prio = getattr(main, "priority", 0)
     key = (dev.index, len(nets))
-    if key not in _LOCKSTEP:
-        _LOCKSTEP[key] = [torch.cuda.Stream(dev, priority=-1) for _ in nets]
-    streams = _LOCKSTEP[key]
+    if key not in _LOCKSTEP or _LOCKSTEP[key][0] != prio:
+        _LOCKSTEP[key] = (prio, [torch.cuda.Stream(dev, priority=prio) for _ in nets])
+    streams = _LOCKSTEP[key][1]
     depth = len(nets[0].body)
     assert all(len(n.body) == depth for n in nets), "lockstep needs backbones of equal depth"
     # stale weight packs are refreshed by ONE launch for every registered parameter (ops._PackPlan): it must run on the caller's
@@ -253,7 +256,7 @@ def forward_taps_lockstep(nets, xs, taps=(2, 6, 20, 23)):
 def lockstep_join(device, n):
     """The caller's stream waits for the lockstep streams (call after backward(), before the optimizers read the gradients)."""
     main = torch.cuda.current_stream(device)
-    for s in _LOCKSTEP.get((device.index, n), ()):
+    for s in _LOCKSTEP.get((device.index, n), (0, ()))[1]:
         main.wait_stream(s)
 
 

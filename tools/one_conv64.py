@@ -18,11 +18,13 @@ pkd, _ = ops._packed(w, "dgrad", torch.bfloat16, 64, 1, 9, 64, 64, 9, 0, 1, 576)
 sc = torch.rand(N, 64, device=dev) + 0.5; sh = torch.randn(N, 64, device=dev); al = torch.rand(64, device=dev)
 stats = torch.zeros(2, N, 64, device=dev)
 slabs = torch.empty(256, 64, 576, device=dev)
+red = torch.zeros(3, N, 64, device=dev)
 for _ in range(int(os.environ.get("REPS", 3))):
     lib.xr_conv64_direct(ptr(x), ptr(pk), None, ptr(y), N, H, H, 0, None, None, None, ptr(stats), None, stream())               # conv1 fwd
     lib.xr_conv64_direct(ptr(x), ptr(pk), None, ptr(y), N, H, H, 0, ptr(sc), ptr(sh), ptr(al), ptr(stats), None, stream())     # conv2 fwd
     lib.xr_conv64_direct(ptr(dy), ptr(pkd), None, ptr(y), N, H, H, 1, None, None, None, None, None, stream())                  # dgrad
     lib.xr_conv64_direct(ptr(dy), ptr(pkd), None, ptr(y), N, H, H, 1, None, None, None, None, ptr(x), stream())                # dgrad + add
+    lib.xr_conv64_direct_bwdred(ptr(dy), ptr(pkd), ptr(y), N, H, H, 1, ptr(x), ptr(sc), ptr(sh), ptr(al), ptr(red), stream())  # dgrad + IN-bwd sums
     lib.xr_conv64_wgrad(ptr(x), ptr(dy), ptr(slabs), N, H, H, 256, None, None, None, stream())
     lib.xr_conv64_wgrad(ptr(x), ptr(dy), ptr(slabs), N, H, H, 256, ptr(sc), ptr(sh), ptr(al), stream())
 torch.cuda.synchronize()
