@@ -1177,6 +1177,15 @@ class _ResBlock64(Function):
                 pe.record()
         else:
             dy1 = _conv64(dc2, pkd2, torch.empty_like(x), transposed=1, tag=tagd)
+        dc1, _, (dg1, db1, da1) = norm_bwd(c1, scale1, shift1, None, a1f, g1f, mean1, invstd1, dy1, g1, b1, a1, False, red=red1)
+        dx = None
+        if need_x:
+            pkd1, _ = _packed(w1, "dgrad", x.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
+            dx = _conv64(dc1, pkd1, torch.empty_like(x), transposed=1, add=dres, tag=tagd)   # + the residual-branch gradient
+        # Both weight gradients go to the side stream after conv1's input gradient is on the main stream.  The persistent direct
+        # kernels of the two streams cannot share a CU (120 KB + 87 KB of LDS): wherever the weight gradients are launched they
+        # displace main-stream convolutions for as long as they run -- launching conv2's between the two input gradients or here
+        # measured the same step time (C3 38.5 ms either way), so the simpler order is kept
         dw2 = None
         if ctx.needs_input_grad[5] and _wanted(w2):
             if _wgrad64_ok(c1, dc2, H, W, 64, H, W, 64, 3, 3, 1, 1, 0):
@@ -1188,11 +1197,6 @@ class _ResBlock64(Function):
                 lib.xr_affine_act(d, ptr(c1), ptr(scale1), ptr(shift1), None, ptr(a1f), ACT_PRELU, ptr(y1), N, HW, C, 1, stream())
                 dw2 = _wgrad(w2, y1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64,
                              64, 576, 0, 1, 9)
-        dc1, _, (dg1, db1, da1) = norm_bwd(c1, scale1, shift1, None, a1f, g1f, mean1, invstd1, dy1, g1, b1, a1, False, red=red1)
-        dx = None
-        if need_x:
-            pkd1, _ = _packed(w1, "dgrad", x.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
-            dx = _conv64(dc1, pkd1, torch.empty_like(x), transposed=1, add=dres, tag=tagd)   # + the residual-branch gradient
         dw1 = None
         if ctx.needs_input_grad[1] and _wanted(w1):
             dw1 = _wgrad(w1, x, dc1, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, _wgrad_split(N * HW, 64, 576), 64, 1, 9, 64, 64, 576,
