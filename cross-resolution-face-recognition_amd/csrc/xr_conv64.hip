@@ -28,7 +28,11 @@
 //     sum (out += ep_add); InstanceNorm + PReLU BACKWARD reductions (EP == 3): when the tensor being written is the gradient
 //     dy1 of y1 = prelu(c1 * scale[n] + shift[n]) -- conv2's input gradient in the FSRNet block -- the stream-out also loads the
 //     matching c1 chunk and accumulates sum dz, sum dz * c1 and the PReLU slope term per image and channel, the three sums of
-//     xr_affine_act_bwd_reduce: that pass (two full-tensor reads) disappears.
+//     xr_affine_act_bwd_reduce: that pass (two full-tensor reads) disappears.  EP == 4 chains two residual blocks in the backward
+//     pass: the kernel computes dout = conv + ep_add (the gradient entering the PREVIOUS block's tail out = prelu(c2 * scale +
+//     shift + x)), but stores dz = dout * prelu'(z) -- the gradient of the tail's pre-activation, which is both that block's
+//     residual-branch gradient and the input of its InstanceNorm backward -- together with the three sums over (dz, c2): the
+//     previous block then needs neither its reduce pass nor the residual half of its apply pass.
 #include "xr_common.h"
 #include <type_traits>
 
@@ -66,7 +70,9 @@ struct DC64P {
   const bf16_t* w;        // [64][576] bf16: row = GEMM output channel, column = tap * 64 + reduction channel
   const float* bias;      // [64] or null
   bf16_t* out;
-  const bf16_t* ep_add;   // laid out like out: residual gradient (EP == 2) or the norm input c1 (EP == 3)
+  const bf16_t* ep_add;   // laid out like out: residual gradient (EP == 2, 4) or the norm input c1 (EP == 3)
+  const bf16_t* ep_c;     // EP == 4: the previous block's c2 (norm input of its tail) and x (its residual input)
+  const bf16_t* ep_x;
   const float* n_scale;   // [N][64] per-image affine applied to the input on load (NORM)
   const float* n_shift;
   const float* n_alpha;   // [64] PReLU slope applied after the affine, or null (no activation)
@@ -85,7 +91,8 @@ struct TileGeo {          // wave-uniform description of one tile
   bool interior;          // the whole halo lies inside the image
 };
 
-// EP: 0 plain, 1 per-image output statistics, 2 out += ep_add, 3 InstanceNorm / PReLU backward reductions of the output
+// EP: 0 plain, 1 per-image output statistics, 2 out += ep_add, 3 InstanceNorm / PReLU backward reductions of the output,
+// 4 out = prelu'(tail) * (conv + ep_add) with the reductions of the previous block's tail
 template <bool TR, bool NORM, int EP>
 __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   constexpr int NPB = 4;   // pixel blocks (32 pixels = 2 image rows x 16 columns) per wave
@@ -125,10 +132,12 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_add =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP >= 2 ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 4 ? p.ep_c : p.in), 0, p.io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 4 ? p.ep_x : p.in), 0, p.io_bytes, 0x00020000);
   float sc[8], sh[8], al[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = 1.f, sh[e] = 0.f, al[e] = 1.f;
-  if ((NORM || EP == 3) && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
+  if ((NORM || EP >= 3) && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
   int n_staged = -1;
 
   auto geo_of = [&](int tl) {
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) bs[e] = 0.f, bss[e] = 0.f, b3[e] = 0.f;
   int n_stats = -1;
-  v4u_t ov[NOUT], addv[NOUT];
+  v4u_t ov[NOUT], addv[NOUT], cv[EP == 4 ? NOUT : 1], xv[EP == 4 ? NOUT : 1];
   auto out_mask = [&](const TileGeo& g, bool live) {   // bit i: row group i of this thread lies inside the image
     unsigned m = 0;
     if (live && g.x0 + ocol < p.W) {
@@ -210,6 +219,12 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   auto add_load = [&](int base, unsigned om, int i) {
     if constexpr (EP >= 2) addv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, out_voff(base, om, i), 0, 0);
   };
+  auto tail_load = [&](int base, unsigned om, int i, int which) {
+    if constexpr (EP == 4) {
+      if (which == 0) cv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, out_voff(base, om, i), 0, 0);
+      else xv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, out_voff(base, om, i), 0, 0);
+    }
+  };
   auto out_read = [&](int i) { ov[i] = *reinterpret_cast<const v4u_t*>(smem + oimg + i * RPP * OPITCH); };
   auto out_store = [&](int base, unsigned om, int i) {
     const unsigned voff = out_voff(base, om, i);
@@ -222,6 +237,38 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
         const float b = __uint_as_float(v[q] & 0xFFFF0000u) + __uint_as_float(addv[i][q] & 0xFFFF0000u);
         o[q] = pack2bf(a, b);
       }
+      v = v4u_t{o[0], o[1], o[2], o[3]};
+    }
+    if constexpr (EP == 4) {
+      const bool ok = (om >> i) & 1u;
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // dout = conv + residual gradient, rounded to bf16 as the tensor the reduce pass would have read
+        const unsigned dw = pack2bf(__uint_as_float(v[q] << 16) + __uint_as_float(addv[i][q] << 16),
+                                    __uint_as_float(v[q] & 0xFFFF0000u) + __uint_as_float(addv[i][q] & 0xFFFF0000u));
+        const unsigned w = ok ? dw : 0u, cw = cv[i][q], xw = xv[i][q];
+        float dzs[2];
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+          const int e = 2 * q + hlf;
+          const float d = hlf ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
+          const float c = hlf ? __uint_as_float(cw & 0xFFFF0000u) : __uint_as_float(cw << 16);
+          const float xr = hlf ? __uint_as_float(xw & 0xFFFF0000u) : __uint_as_float(xw << 16);
+          const float z = c * sc[e] + sh[e] + xr;
+          const float dz = z > 0.f ? d : d * al[e];
+          bs[e] += dz;
+          bss[e] += dz * c;
+          b3[e] += z <= 0.f ? d * z : 0.f;
+          dzs[hlf] = dz;
+        }
+        o[q] = pack2bf(dzs[0], dzs[1]);
+        asm volatile("" : "+v"(o[q]));
+      }
+      // pin the sums to THIS slot as well: left free, LLVM sinks the 24 accumulator updates of every row group towards the flush
+      // and the kernel spills 220 registers to scratch (4x slower)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bs[e]), "+v"(bss[e]), "+v"(b3[e]));
       v = v4u_t{o[0], o[1], o[2], o[3]};
     }
     __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, voff, 0, 0);
@@ -262,14 +309,14 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
       float c3 = 0.f;
-      if constexpr (EP == 3) {
+      if constexpr (EP >= 3) {
         c3 = b3[e];
         c3 += __shfl_xor(c3, 8, 64); c3 += __shfl_xor(c3, 16, 64); c3 += __shfl_xor(c3, 32, 64);
       }
       if (lane < 8 && n_stats >= 0) {
         atomicAdd(p.stats + (size_t)n_stats * 64 + cc * 8 + e, a);
         atomicAdd(p.stats + ((size_t)p.N + n_stats) * 64 + cc * 8 + e, b);
-        if constexpr (EP == 3) atomicAdd(p.stats + ((size_t)2 * p.N + n_stats) * 64 + cc * 8 + e, c3);
+        if constexpr (EP >= 3) atomicAdd(p.stats + ((size_t)2 * p.N + n_stats) * 64 + cc * 8 + e, c3);
       }
       bs[e] = 0.f;
       bss[e] = 0.f;
@@ -277,10 +324,10 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     }
   };
   auto stats_image = [&](int n) {   // wave-uniform: called before the first stream-out item of a tile
-    if ((EP == 1 || EP == 3) && n != n_stats) {
+    if ((EP == 1 || EP >= 3) && n != n_stats) {
       if (n_stats >= 0) flush_stats();
       n_stats = n;
-      if constexpr (EP == 3) {      // coefficients of z = c1 * scale + shift for the image being streamed out
+      if constexpr (EP >= 3) {      // coefficients of z = c1 * scale + shift for the image being streamed out
         ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
         ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
       }
@@ -355,18 +402,43 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     auto side = [&](auto K) {
       constexpr int k = decltype(K)::value;   // 0 .. NSLOT - 1 (144 slots per wave and tile)
       // global loads of tile t+1: slots 1, 4, ..., 31
-      if constexpr (k >= 1 && k < 1 + 3 * NCH && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
+      if constexpr (EP == 4) {
+        // two staging phases (chunks 0-5 load at 1.. and are written at 60..; chunks 6-10 load at 75.., written at 122..): 24
+        // staging registers live instead of 44 -- this variant also keeps three epilogue tensors in flight
+        if constexpr (k >= 1 && k < 1 + 3 * 6 && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
+        if constexpr (k >= 75 && k < 75 + 3 * (NCH - 6) && (k - 75) % 3 == 0) load_chunk(nbase, vm, 6 + (k - 75) / 3);
+        if constexpr (k >= 60 && k < 60 + 4 * 6 && (k - 60) % 4 == 0) write_chunk(buf ^ 1, (k - 60) / 4);
+        if constexpr (k >= 122 && k < 122 + 4 * (NCH - 6) && (k - 122) % 4 == 0) write_chunk(buf ^ 1, 6 + (k - 122) / 4);
+      } else {
+        if constexpr (k >= 1 && k < 1 + 3 * NCH && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
+      }
       // stream-out of tile t-1, row group i: (residual load at 33 + 6 i,) LDS read at RD + ST i, store 3 slots later
+      if constexpr (EP == 4) {
+        // three epilogue loads per row group (residual gradient, tail c2, tail x): only TWO groups are kept in flight (groups 0, 1
+        // load at 20.. / 26.., leave at 61 / 67; groups 2, 3 load at 64.. / 70.., leave at 107 / 113) -- with all four live
+        // the kernel spilled 217 registers to scratch and ran 4x slower
+        static_for<0, NOUT>([&](auto I) {
+          constexpr int i = decltype(I)::value;
+          constexpr int ld = i == 0 ? 20 : (i == 1 ? 26 : (i == 2 ? 64 : 70));
+          constexpr int rd = i == 0 ? 58 : (i == 1 ? 64 : (i == 2 ? 104 : 110));
+          if constexpr (k == ld) add_load(pbase, om, i);
+          if constexpr (k == ld + 1) tail_load(pbase, om, i, 0);
+          if constexpr (k == ld + 2) tail_load(pbase, om, i, 1);
+          if constexpr (k == rd) out_read(i);
+          if constexpr (k == rd + 3) out_store(pbase, om, i);
+        });
+      } else {
       constexpr int RD = EP >= 2 ? 69 : 36, ST = EP >= 2 ? 6 : 8;
       if constexpr (EP >= 2 && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
       if constexpr (k >= RD && k < RD + ST * NOUT && (k - RD) % ST == 0) out_read((k - RD) / ST);
       if constexpr (k >= RD + 3 && k < RD + 3 + ST * NOUT && (k - RD - 3) % ST == 0) out_store(pbase, om, (k - RD - 3) / ST);
+      }
       // transform + LDS write of tile t+1 (the loads left >= 55 slots earlier).  NORM: chunk i is transformed two channels
       // at a time at slots 56 + 8 i + {0, 2, 4, 6} and written at 56 + 8 i + 7; otherwise written at 100 + 4 i
       if constexpr (NORM) {
         if constexpr (k >= 56 && k < 56 + 8 * NCH && (k - 56) % 8 % 2 == 0) xform_part(vm, (k - 56) / 8, (k - 56) % 8 / 2);
         if constexpr (k >= 56 && k < 56 + 8 * NCH && (k - 56) % 8 == 7) write_chunk(buf ^ 1, (k - 56) / 8);
-      } else {
+      } else if constexpr (EP != 4) {
         if constexpr (k >= 100 && k < 100 + 4 * NCH && (k - 100) % 4 == 0) write_chunk(buf ^ 1, (k - 100) / 4);
       }
     };
@@ -422,14 +494,18 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   {
     const unsigned om = out_mask(prv, true);
 #pragma unroll
-    for (int i = 0; i < NOUT; ++i) add_load(prv.base, om, i);
+    for (int i = 0; i < NOUT; ++i) {
+      add_load(prv.base, om, i);
+      tail_load(prv.base, om, i, 0);
+      tail_load(prv.base, om, i, 1);
+    }
 #pragma unroll
     for (int i = 0; i < NOUT; ++i) {
       out_read(i);
       out_store(prv.base, om, i);
     }
   }
-  if (EP == 1 || EP == 3) flush_stats();
+  if (EP == 1 || EP >= 3) flush_stats();
 }
 
 template <bool TR, bool NORM, int EP>
@@ -449,8 +525,12 @@ int launch_dconv64(DC64P& p, int grid, hipStream_t st) {
 template <bool TR, bool NORM>
 int launch_dconv64_ep(DC64P& p, int grid, hipStream_t st) {
   if (p.stats != nullptr && p.ep_add != nullptr) {
-    if constexpr (!NORM) return launch_dconv64<TR, false, 3>(p, grid, st);
-    else return XR_E_INVALID;
+    if constexpr (!NORM) {
+      if (p.ep_c != nullptr) return launch_dconv64<TR, false, 4>(p, grid, st);
+      return launch_dconv64<TR, false, 3>(p, grid, st);
+    } else {
+      return XR_E_INVALID;
+    }
   }
   if (p.stats != nullptr) return launch_dconv64<TR, NORM, 1>(p, grid, st);
   if (p.ep_add != nullptr) return launch_dconv64<TR, NORM, 2>(p, grid, st);
@@ -511,6 +591,23 @@ extern "C" int xr_conv64_direct_bwdred(const void* in, const void* wpack, void* 
   DC64P p{};
   p.in = (const bf16_t*)in; p.w = (const bf16_t*)wpack; p.out = (bf16_t*)out; p.ep_add = (const bf16_t*)red_src;
   p.n_scale = red_scale; p.n_shift = red_shift; p.n_alpha = red_alpha; p.stats = red;
+  p.N = N; p.H = H; p.W = W;
+  p.io_bytes = (unsigned)io_bytes;
+  return dconv64_run(p, transposed, false, (hipStream_t)stream);
+}
+
+extern "C" int xr_conv64_direct_tailred(const void* in, const void* wpack, void* out, int N, int H, int W, int transposed,
+                                        const void* ep_add, const void* tail_c, const void* tail_x, const float* tail_scale,
+                                        const float* tail_shift, const float* tail_alpha, float* red, void* stream) {
+  XR_CHECK_ARG(in && wpack && out && N > 0 && H > 0 && W > 0, "xr_conv64_direct_tailred: null pointer / non-positive dimension");
+  XR_CHECK_ARG(ep_add && tail_c && tail_x && tail_scale && tail_shift && red,
+               "xr_conv64_direct_tailred: needs the residual gradient, the tail's c / x / scale / shift and the sums");
+  const long long io_bytes = (long long)N * H * W * 64 * 2;
+  XR_CHECK_ARG(io_bytes < (1ll << 31), "xr_conv64_direct_tailred: tensor larger than 2 GiB");
+  DC64P p{};
+  p.in = (const bf16_t*)in; p.w = (const bf16_t*)wpack; p.out = (bf16_t*)out; p.ep_add = (const bf16_t*)ep_add;
+  p.ep_c = (const bf16_t*)tail_c; p.ep_x = (const bf16_t*)tail_x;
+  p.n_scale = tail_scale; p.n_shift = tail_shift; p.n_alpha = tail_alpha; p.stats = red;
   p.N = N; p.H = H; p.W = W;
   p.io_bytes = (unsigned)io_bytes;
   return dconv64_run(p, transposed, false, (hipStream_t)stream);

@@ -133,8 +133,7 @@ class Course_SR_Network(nn.Module):
 
     def f(self, x):
         y = self.bn_mid.f(self.conv_input.f(x), act="prelu", alpha=self.relu.weight)
-        for _ in range(3):  # the SAME three blocks applied three times (model/FSRnet.py:331-333)
-            y = xnn.run_seq(self.residual, y)
+        y = xnn.res_trunk(self.residual, y, 3)   # the SAME three blocks applied three times (model/FSRnet.py:331-333)
         y = self.bn_mid.f(y)
         return y, self.conv_mid.f(y)
 
@@ -156,8 +155,7 @@ class Fine_SR_Encoder(Course_SR_Network):
 
     def f(self, x):
         y = self.bn_mid.f(self.conv_input.f(x), act="prelu", alpha=self.relu.weight)
-        for _ in range(3):
-            y = xnn.run_seq(self.residual, y)
+        y = xnn.res_trunk(self.residual, y, 3)
         return self.bn_mid.f(self.conv_end.f(y), act="prelu", alpha=self.relu.weight)
 
     def forward(self, x):
@@ -213,8 +211,7 @@ class Fine_SR_Decoder(nn.Module):
     def f(self, x):
         y = self.bn_mid.f(self.conv_input.f(x), act="prelu", alpha=self.relu.weight)
         y = self.bn_mid.f(self.deconv.f(y), act="prelu", alpha=self.relu.weight)
-        for _ in range(3):
-            y = xnn.run_seq(self.residual, y)
+        y = xnn.res_trunk(self.residual, y, 3)
         return self.conv_out.f(self.bn_mid.f(y))
 
     def forward(self, x):

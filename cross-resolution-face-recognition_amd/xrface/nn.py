@@ -251,6 +251,19 @@ def run_seq(seq, buf):
     return buf
 
 
+def res_trunk(seq, buf, times):
+    """``times`` passes over an nn.Sequential of FSRNet residual blocks (model/FSRnet.py:331-333 applies the same three blocks three
+    times).  bf16 64-channel blocks run as ONE chained op (ops._ResTrunk64: consecutive blocks hand the tail's pre-activation
+    gradient to each other in the backward pass); anything else runs block by block."""
+    blocks = list(seq)
+    if (all(hasattr(b, a) for b in blocks for a in ("conv1", "in1", "relu", "conv2", "in2", "relu_out"))
+            and all(b.in1.weight is not None and b.in2.weight is not None for b in blocks) and ops.res_trunk64_ok(buf, blocks)):
+        return ops.res_trunk64(buf, blocks, times)
+    for _ in range(times):
+        buf = run_seq(seq, buf)
+    return buf
+
+
 def conv_bn(conv, bn, buf, res=None, act=None, alpha=None, pass_through=False):
     """conv -> BatchNorm(+residual, +activation) with the batch statistics taken in the convolution's epilogue.
     pass_through: also return buf' (aliasing buf) for an identity branch whose gradient the conv's dgrad epilogue sums in."""

@@ -19,7 +19,8 @@ EPS = 1e-5
 import os as _os
 _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
         "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2")),
-        "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1"))}
+        "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
+        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1"))}
 
 
 def set_compute_dtype(dtype):
@@ -1208,6 +1209,190 @@ def resblock64(x, conv1, in1, relu, conv2, in2, relu_out):
     """conv1 / conv2: xrface.nn.Conv2d (64 -> 64, 3x3, bias-free), in1 / in2: affine InstanceNorm2d, relu / relu_out: PReLU(64)."""
     return _ResBlock64.apply(x, conv1.weight, in1.weight, in1.bias, relu.weight, conv2.weight, in2.weight, in2.bias,
                              relu_out.weight, in1.eps)
+
+
+class _ResTrunk64(Function):
+    """``times`` x [block_0 .. block_{nb-1}] of FSRNet residual blocks (model/FSRnet.py:331-333: the same three blocks applied
+    three times) on 64 channels in bf16 as ONE autograd op.  Forward = the _ResBlock64 forward per application.  Backward chains
+    consecutive applications: conv1's input-gradient kernel of application i + 1 does not store the gradient dout_i of the
+    previous application's output but dz_i = dout_i * prelu'(tail_i) -- the gradient of that tail's pre-activation -- plus the three
+    InstanceNorm-backward sums over it (xr_conv64_direct_tailred).  dz_i is at once application i's residual-branch gradient and
+    the input of IN2's backward, so application i runs no reduce pass for its tail and a two-input apply pass (dz, c2 -> dc2)
+    instead of the three-input, two-output one: 18 tensor passes per application instead of 21.  Only the last application
+    (whose dout comes from autograd) takes the standard path.  Block parameters: (w1, g1, b1, a1, w2, g2, b2, ao) per block."""
+
+    @staticmethod
+    def forward(ctx, x, times, nb, eps, *params):
+        x = _c(x)
+        N, H, W, C = x.shape
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        HW = H * W
+        tag = ("fwd", 64, 64, H, W, 3, 1)
+        fl = lambda t: _c(t.detach().float())
+        blocks = [params[8 * b:8 * b + 8] for b in range(nb)]
+        pk = [(_packed(p_[0], "fwd", x.dtype, 64, 1, 9, 64, 64, 576, 0, 1, 9)[0], _packed(p_[4], "fwd", x.dtype, 64, 1, 9, 64, 64, 576, 0, 1, 9)[0])
+              for p_ in blocks]
+        small = [[fl(t) for t in (p_[1], p_[2], p_[3], p_[5], p_[6], p_[7])] for p_ in blocks]     # g1 b1 a1 g2 b2 ao
+
+        def finalize(sums, gm, bt):
+            mean, invstd = torch.empty((N, C), **f32), torch.empty((N, C), **f32)
+            scale, shift = torch.empty((N, C), **f32), torch.empty((N, C), **f32)
+            lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift), None, None, N, HW, C, eps,
+                                 0.0, 1, stream())
+            return mean, invstd, scale, shift
+
+        saved = [x]
+        cur = x
+        for i in range(times * nb):
+            b = i % nb
+            g1f, b1f, a1f, g2f, b2f, aof = small[b]
+            st1 = zeros_f32((2, N, C), dev)
+            c1 = _conv64(cur, pk[b][0], torch.empty_like(cur), stats=st1, tag=tag)
+            mean1, invstd1, scale1, shift1 = finalize(st1, g1f, b1f)
+            st2 = zeros_f32((2, N, C), dev)
+            c2 = _conv64(c1, pk[b][1], torch.empty_like(cur), scale=scale1, shift=shift1, alpha=a1f, stats=st2, tag=tag)
+            mean2, invstd2, scale2, shift2 = finalize(st2, g2f, b2f)
+            out = torch.empty_like(cur)
+            lib.xr_affine_act(dt(cur), ptr(c2), ptr(scale2), ptr(shift2), ptr(cur), ptr(aof), ACT_PRELU, ptr(out), N, HW, C, 1, stream())
+            saved += [c1, c2, mean1, invstd1, scale1, shift1, mean2, invstd2, scale2, shift2, out]
+            cur = out
+        for sm in small:
+            saved += sm
+        ctx.save_for_backward(*saved)
+        ctx.prefs = blocks
+        ctx.shape = (times, nb)
+        return cur
+
+    @staticmethod
+    def backward(ctx, dout):
+        sv = ctx.saved_tensors
+        times, nb = ctx.shape
+        A = times * nb
+        blocks = ctx.prefs
+        x0 = sv[0]
+        per = [sv[1 + 11 * i: 1 + 11 * (i + 1)] for i in range(A)]     # c1 c2 mean1 invstd1 scale1 shift1 mean2 invstd2 scale2 shift2 out
+        small = [sv[1 + 11 * A + 6 * b: 1 + 11 * A + 6 * (b + 1)] for b in range(nb)]
+        N, H, W, C = x0.shape
+        HW = H * W
+        dev = x0.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        d = dt(x0)
+        g = _c(dout)
+        if g.dtype != x0.dtype:
+            g = g.to(x0.dtype)
+        tagd = ("dgrad", 64, 64, H, W, 3, 1)
+        need_x = ctx.needs_input_grad[0]
+        # small-gradient accumulators, one per parameter, shared by the applications of a block (the coefficient kernel adds)
+        acc = {}
+
+        def small_acc(p_):
+            if id(p_) not in acc:
+                t_ = _direct(p_)
+                acc[id(p_)] = (t_, t_ if t_ is not None else zeros_f32((C,), dev))
+            return acc[id(p_)]
+
+        dws = {}
+
+        def add_dw(p_, v):
+            if v is not None:
+                dws[id(p_)] = v if id(p_) not in dws else dws[id(p_)] + v
+
+        red_tail = None     # sums of the CURRENT application's tail, when they came out of the previous kernel's epilogue
+        for i in range(A - 1, -1, -1):
+            b = i % nb
+            w1, g1, b1, a1, w2, g2, b2, ao = blocks[b]
+            g1f, b1f, a1f, g2f, b2f, aof = small[b]
+            c1, c2, mean1, invstd1, scale1, shift1, mean2, invstd2, scale2, shift2, _ = per[i]
+            xin = x0 if i == 0 else per[i - 1][10]
+            # ---- tail: out = prelu_out(IN2(c2) + xin)
+            (t_g, dg), (t_b, db), (t_a, da) = small_acc(g2), small_acc(b2), small_acc(ao)
+            coef = torch.empty((3, N, C), **f32)
+            dc2 = torch.empty_like(x0)
+            if red_tail is None:
+                red = zeros_f32((3, N, C), dev)
+                lib.xr_affine_act_bwd_reduce(d, ptr(c2), ptr(scale2), ptr(shift2), ptr(xin), ptr(aof), ACT_PRELU, ptr(g), ptr(red), N, HW,
+                                             C, 1, stream())
+                lib.xr_norm_bwd_coeffs(ptr(red), ptr(g2f), ptr(mean2), ptr(invstd2), ptr(coef), ptr(dg), ptr(db), ptr(da), N, HW, C, 1,
+                                       stream())
+                dz = torch.empty_like(x0)
+                lib.xr_affine_act_bwd_apply(d, ptr(c2), ptr(scale2), ptr(shift2), ptr(xin), ptr(aof), ACT_PRELU, ptr(g), ptr(coef), ptr(dc2),
+                                            ptr(dz), N, HW, C, 1, None, stream())
+            else:
+                # g already IS dz (the epilogue of the next application's conv1 input gradient applied prelu' and took the sums)
+                lib.xr_norm_bwd_coeffs(ptr(red_tail), ptr(g2f), ptr(mean2), ptr(invstd2), ptr(coef), ptr(dg), ptr(db), ptr(da), N, HW, C, 1,
+                                       stream())
+                dz = g
+                lib.xr_affine_act_bwd_apply(d, ptr(c2), None, None, None, None, ACT_NONE, ptr(dz), ptr(coef), ptr(dc2), None, N, HW, C, 1,
+                                            None, stream())
+            for p_ in (g2, b2, ao):
+                if acc[id(p_)][0] is not None:
+                    _direct_done(p_)
+            # ---- conv2's input gradient + the sums of IN1 / PReLU's backward
+            pkd2, _ = _packed(w2, "dgrad", x0.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
+            red1 = zeros_f32((3, N, C), dev)
+            dy1 = torch.empty_like(x0)
+            pe = _probe_begin(tagd)
+            lib.xr_conv64_direct_bwdred(ptr(dc2), ptr(pkd2), ptr(dy1), N, H, W, 1, ptr(c1), ptr(scale1), ptr(shift1), ptr(a1f), ptr(red1),
+                                        stream())
+            if pe is not None:
+                pe.record()
+            (t_g1, dg1), (t_b1, db1), (t_a1, da1) = small_acc(g1), small_acc(b1), small_acc(a1)
+            coef1 = torch.empty((3, N, C), **f32)
+            lib.xr_norm_bwd_coeffs(ptr(red1), ptr(g1f), ptr(mean1), ptr(invstd1), ptr(coef1), ptr(dg1), ptr(db1), ptr(da1), N, HW, C, 1,
+                                   stream())
+            for p_ in (g1, b1, a1):
+                if acc[id(p_)][0] is not None:
+                    _direct_done(p_)
+            dc1 = torch.empty_like(x0)
+            lib.xr_affine_act_bwd_apply(d, ptr(c1), ptr(scale1), ptr(shift1), None, ptr(a1f), ACT_PRELU, ptr(dy1), ptr(coef1), ptr(dc1), None,
+                                        N, HW, C, 1, None, stream())
+            # ---- conv1's input gradient (+ the residual-branch gradient dz); chained into the previous application's tail
+            pkd1, _ = _packed(w1, "dgrad", x0.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)
+            if i > 0:
+                pc2, pscale2, pshift2 = per[i - 1][1], per[i - 1][8], per[i - 1][9]
+                pxin = x0 if i == 1 else per[i - 2][10]
+                paof = small[(i - 1) % nb][5]
+                red_tail = zeros_f32((3, N, C), dev)
+                nxt = torch.empty_like(x0)
+                pe = _probe_begin(tagd)
+                lib.xr_conv64_direct_tailred(ptr(dc1), ptr(pkd1), ptr(nxt), N, H, W, 1, ptr(dz), ptr(pc2), ptr(pxin), ptr(pscale2),
+                                             ptr(pshift2), ptr(paof), ptr(red_tail), stream())
+                if pe is not None:
+                    pe.record()
+                g = nxt
+            elif need_x:
+                g = _conv64(dc1, pkd1, torch.empty_like(x0), transposed=1, add=dz, tag=tagd)
+            else:
+                g = None
+            # ---- weight gradients (side stream when accumulating in place)
+            if _wanted(w2):
+                add_dw(w2, _wgrad(w2, c1, dc2, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, 0, 64, 1, 9, 64, 64, 576, 0, 1, 9,
+                                  xform=(scale1, shift1, a1f)))
+            if _wanted(w1):
+                add_dw(w1, _wgrad(w1, xin, dc1, N, H, W, 64, H, W, 64, 3, 3, 1, 1, 0, 64, 576, 0, 64, 1, 9, 64, 64, 576, 0, 1, 9))
+        grads = []
+        for b in range(nb):
+            w1, g1, b1, a1, w2, g2, b2, ao = blocks[b]
+            sm = lambda p_: None if (id(p_) not in acc or acc[id(p_)][0] is not None) else acc[id(p_)][1]
+            grads += [dws.get(id(w1)), sm(g1), sm(b1), sm(a1), dws.get(id(w2)), sm(g2), sm(b2), sm(ao)]
+        return (g, None, None, None, *grads)
+
+
+def res_trunk64_ok(x, blocks):
+    """bf16 64-channel NHWC input with W % 8 == 0 and W <= 112 and every block a 64 -> 64 FSRNet residual block: the chained trunk op."""
+    if not (_cfg["direct64"] and _cfg["res_trunk"] and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 64
+            and x.shape[2] % 8 == 0 and x.shape[2] <= 112 and x.numel() * 2 < (1 << 31) and not _graph["capturing"]):
+        return False
+    return all(tuple(b.conv1.weight.shape) == (64, 64, 3, 3) and tuple(b.conv2.weight.shape) == (64, 64, 3, 3) for b in blocks)
+
+
+def res_trunk64(x, blocks, times):
+    """``times`` passes over ``blocks`` (xrface.model.FSRnet._Residual_Block modules) as one chained op."""
+    params = []
+    for b in blocks:
+        params += [b.conv1.weight, b.in1.weight, b.in1.bias, b.relu.weight, b.conv2.weight, b.in2.weight, b.in2.bias, b.relu_out.weight]
+    return _ResTrunk64.apply(x, times, len(blocks), blocks[0].in1.eps, *params)
 
 
 # ------------------------------------------------------------------------------------------------- SE

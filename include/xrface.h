@@ -132,6 +132,18 @@ int xr_conv64_direct(const void* in, const void* wpack, const float* bias, void*
 int xr_conv64_direct_bwdred(const void* in, const void* wpack, void* out, int N, int H, int W, int transposed, const void* red_src,
                             const float* red_scale, const float* red_shift, const float* red_alpha, float* red, void* stream);
 
+/* Two FSRNet residual blocks chained in the backward pass.  The convolution is conv1's input gradient of block i + 1; with
+ * dout = conv + ep_add (ep_add = that block's residual-branch gradient) being the gradient that enters the tail
+ * out = prelu(tail_c * tail_scale[n] + tail_shift[n] + tail_x, tail_alpha) of block i (model/FSRnet.py:90-98), the kernel stores
+ *   out = dz = dout * (z > 0 ? 1 : alpha),  z = c * scale + shift + x           (dout rounded to bf16 first)
+ * -- the gradient of the tail's pre-activation: block i's residual-branch gradient AND the input of its InstanceNorm backward --
+ * and accumulates red[0] += sum dz, red[1] += sum dz * c, red[2] += sum dout * z * [z <= 0] per image and channel
+ * (xr_affine_act_bwd_reduce(x = c, res = x, dy = dout)).  Block i then runs neither that reduce pass nor the residual half of its
+ * apply pass.  red [3][N][64] fp32, zeroed by the caller; all tensors laid out like out. */
+int xr_conv64_direct_tailred(const void* in, const void* wpack, void* out, int N, int H, int W, int transposed, const void* ep_add,
+                             const void* tail_c, const void* tail_x, const float* tail_scale, const float* tail_shift,
+                             const float* tail_alpha, float* red, void* stream);
+
 /* Weight gradient (aten::convolution_backward weight part; same call sites as above).
  * slab[s][k][t*C + c] = sum_{m in slice s} dy[m][k] * gather(in)[m][t][c]   (fp32, PACKED layout [K][Kg])
  * where m runs over the N*Ho*Wo pixels of dy (row pitch ldy), split into `split` contiguous slices, and gather()

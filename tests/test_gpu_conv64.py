@@ -348,3 +348,51 @@ def test_direct_conv64_backward_reduction_epilogue(case, with_alpha):
     assert torch.equal(out, out0)
     for k in range(2 if not with_alpha else 3):        # slope 1: the PReLU slope term is not meaningful
         assert rel(red[k], ref[k]) < 2e-5, (k, rel(red[k], ref[k]))
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (3, 24, 40), (2, 112, 112)])
+@pytest.mark.parametrize("flat", [False, True])
+def test_chained_residual_trunk_matches_block_by_block(shape, flat):
+    """ops._ResTrunk64 (three blocks x three passes as one op, tails chained through xr_conv64_direct_tailred) against the same
+    blocks applied one _ResBlock64 at a time, both in bf16, and both against the fp32 parity mode of the same nine applications:
+    the chained path must be as close to fp32 as the unchained one (it rounds the tail gradient to bf16 once more, nothing else
+    differs).  With FlatParams the gradients are accumulated in place at nine use sites per parameter."""
+    import xrface
+    from xrface import ops, parallel
+    from xrface.model.FSRnet import _Residual_Block
+    from xrface.nn import res_trunk
+    import torch.nn as nn
+    N, H, W = shape
+    x = rnd(f"trx{shape}", N, 64, H, W).bfloat16().float().to(DEV)
+    gout = rnd(f"trg{shape}", N, 64, H, W).bfloat16().float().to(DEV)
+    res = {}
+    try:
+        for mode in ("trunk", "blocks", "fp32"):
+            xrface.set_compute_dtype(torch.float32 if mode == "fp32" else torch.bfloat16)
+            seq = nn.Sequential(*[_Residual_Block(64) for _ in range(3)])
+            for i, b in enumerate(seq):
+                b.load_state_dict(G.det_state_dict(b.state_dict(), 10 + i))
+            seq.to(DEV)
+            if flat:
+                parallel.FlatParams(seq.parameters()).zero_grad()
+            ops._cfg["res_trunk"] = 1 if mode == "trunk" else 0
+            xin = x.clone().requires_grad_(True)
+            y = ops.leave(res_trunk(seq, ops.enter(xin), 3))
+            y.backward(gout)
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            res[mode] = (y.detach().float(), xin.grad.detach().float(), {k: p.grad.detach().float().clone() for k, p in seq.named_parameters()})
+    finally:
+        ops._cfg["res_trunk"] = 1
+        xrface.set_compute_dtype(torch.float32)
+    cos = lambda a, b: float((a.double().flatten() @ b.double().flatten()) / (a.double().norm() * b.double().norm() + 1e-30))
+    yt, dxt, gt = res["trunk"]
+    yb, dxb, gb = res["blocks"]
+    yr, dxr, gr = res["fp32"]
+    assert cos(yt, yb) > 0.99995 and rel(yt, yb) < 3e-2        # same forward arithmetic up to the order of the fp32 statistic atomics
+    ct, cb = cos(dxt, dxr), cos(dxb, dxr)
+    assert ct > 0.998 and ct > cb - 1e-3, (ct, cb)
+    for k in gr:
+        ct, cb = cos(gt[k], gr[k]), cos(gb[k], gr[k])
+        assert ct > 0.99 and ct > cb - 5e-3, (k, ct, cb)
+        assert cos(gt[k], gb[k]) > 0.995, (k, cos(gt[k], gb[k]))
