@@ -606,6 +606,71 @@ def test_c4_full_size_bf16_properties():
         xrface.set_compute_dtype(torch.float32)
 
 
+def test_c3_full_size_bf16_properties():
+    """C3 at BASELINE's per-GPU batch (128, bf16: the chained residual trunks, the direct kernels with every epilogue, the
+    row-walking weight gradients, the side stream): size-independent properties.  (1) on a 32-image slice the bf16 losses agree
+    with the fp32 parity mode (pinned to the reference fixture at N = 2) and the four networks' gradients point the same way;
+    (2) at N = 128 the step is repeatable; (3) four optimizer steps on a fixed batch reduce the summed loss."""
+    import xrface
+    from xrface import parallel
+    from xrface.model import FSRnet
+    from xrface.steps import fhn_step_fused
+    torch.manual_seed(41)
+    fhn = {"coarse": FSRnet.Course_SR_Network().to(DEV), "prior": FSRnet.Prior_Estimation_Network().to(DEV),
+           "encoder": FSRnet.Fine_SR_Encoder().to(DEV), "decoder": FSRnet.Fine_SR_Decoder().to(DEV)}
+    g = torch.Generator(device=DEV); g.manual_seed(9)
+    n = 128
+    lo = torch.randn(n, 3, 14, 14, device=DEV, generator=g)
+    hr = torch.nn.functional.interpolate(lo, size=(112, 112), mode="bilinear").clamp_(-1, 1).contiguous()
+    lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 7), size=(112, 112), mode="bilinear").contiguous()
+    hm = torch.rand(n, 28, 28, device=DEV, generator=g)
+    par = torch.randint(0, 11, (n, 1, 28, 28), device=DEV, generator=g)
+    order = ("coarse", "encoder", "prior", "decoder")
+    flat_of = lambda: {k: torch.cat([p_.grad.detach().float().flatten() for p_ in fhn[k].parameters() if p_.grad is not None]) for k in order}
+    clear = lambda: [setattr(p_, "grad", None) for k in order for p_ in fhn[k].parameters()]
+    try:
+        xrface.set_compute_dtype(torch.float32)
+        l32, _ = fhn_step_fused(fhn, lr[:32], hr[:32], hm[:32], par[:32])
+        g32 = flat_of()
+        clear()
+        xrface.set_compute_dtype(torch.bfloat16)
+        l16, _ = fhn_step_fused(fhn, lr[:32], hr[:32], hm[:32], par[:32])
+        g16 = flat_of()
+        clear()
+        for k in order:
+            c = float(torch.nn.functional.cosine_similarity(g16[k], g32[k], dim=0))
+            print(f"[c3 N=32] {k}: loss f32 {l32[k].item():.4f} bf16 {l16[k].item():.4f}; gradient cosine bf16 vs f32 {c:.4f}")
+            assert abs(l16[k].item() - l32[k].item()) < 3e-2 * abs(l32[k].item()), k
+            # the encoder / prior receive their gradient through the whole decoder (27 InstanceNorm layers downstream): bf16
+            # re-rounding weighs more on them (measured 0.965 / see the printed values) than on the coarse net and the decoder
+            assert c > (0.9 if k in ("encoder", "prior") else 0.97), (k, c)
+        flats = {k: parallel.FlatParams(fhn[k].parameters()) for k in order}
+        la, _ = fhn_step_fused(fhn, lr, hr, hm, par)
+        torch.cuda.synchronize()
+        ga = {k: flats[k].grad.clone() for k in order}
+        for f in flats.values():
+            f.zero_grad()
+        lb, _ = fhn_step_fused(fhn, lr, hr, hm, par)
+        torch.cuda.synchronize()
+        for k in order:
+            c = float(torch.nn.functional.cosine_similarity(flats[k].grad, ga[k], dim=0))
+            assert abs(lb[k].item() - la[k].item()) < 5e-3 * abs(la[k].item()), k
+            assert c > 0.99, (k, c)
+        opts = {k: parallel.FusedRMSprop(flats[k], lr=2e-5, alpha=0.99, weight_decay=1e-5) for k in order}
+        hist = []
+        for _ in range(4):
+            ls, _ = fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts)
+            hist.append({k: v.item() for k, v in ls.items()})
+        print(f"[c3 N=128 bf16] coarse / decoder loss over 4 steps on a fixed batch: {[round(h['coarse'], 2) for h in hist]} / "
+              f"{[round(h['decoder'], 2) for h in hist]}")
+        # the two pixel losses are the well-conditioned ones (the prior's landmark loss against a random heat-map is ~6e5 at
+        # initialisation and oscillates under RMSprop at any step size that moves the others)
+        assert all(v == v for h in hist for v in h.values())
+        assert hist[-1]["coarse"] < hist[0]["coarse"] and hist[-1]["decoder"] < hist[0]["decoder"]
+    finally:
+        xrface.set_compute_dtype(torch.float32)
+
+
 def test_fhn_step_fused_equals_literal_and_direct_mode():
     """fhn_step_fused (one backward pass) == fhn_step (one partial traversal per (loss_k, theta_k) pair), and both stay
     correct when the generators live in FlatParams(direct=True) buffers -- the literal form must then not let the traversal
