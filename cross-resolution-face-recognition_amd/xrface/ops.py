@@ -1382,7 +1382,7 @@ class _ResTrunk64(Function):
 def res_trunk64_ok(x, blocks):
     """bf16 64-channel NHWC input with W % 8 == 0 and W <= 112 and every block a 64 -> 64 FSRNet residual block: the chained trunk op."""
     if not (_cfg["direct64"] and _cfg["res_trunk"] and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 64
-            and x.shape[2] % 8 == 0 and x.shape[2] <= 112 and x.numel() * 2 < (1 << 31) and not _graph["capturing"]):
+            and x.shape[2] % 8 == 0 and x.shape[2] <= 112 and x.numel() * 2 < (1 << 31)):
         return False
     return all(tuple(b.conv1.weight.shape) == (64, 64, 3, 3) and tuple(b.conv2.weight.shape) == (64, 64, 3, 3) for b in blocks)
 
