@@ -300,10 +300,12 @@ extern "C" int xr_conv_wgrad_rows(const void* in, const void* dy, float* slabs, 
   hipStream_t st = (hipStream_t)stream;
   const int ncu = cu_count_rows();
   if (stride == 1) {
+    // rows per step: measured per plan (tools/wgrad_rows_bench.py): 14 / 7 / 3 rows beat 16 / 8 / 4 on the narrow plans, two rows per
+    // step beat one on the 112-wide plan (966 vs 777 TFLOP/s at 64 -> 64, batch 256: half the barriers per MFMA)
     if (Wo <= 16) return launch_rows<1, 14, 1>(p, max_slabs, ncu, st);
     if (Wo <= 32) return launch_rows<2, 7, 1>(p, max_slabs, ncu, st);
     if (Wo <= 64) return launch_rows<4, 3, 1>(p, max_slabs, ncu, st);
-    return launch_rows<7, 1, 1>(p, max_slabs, ncu, st);
+    return launch_rows<7, 2, 1>(p, max_slabs, ncu, st);
   }
   if (Wo <= 16) return launch_rows<1, 6, 2>(p, max_slabs, ncu, st);
   if (Wo <= 32) return launch_rows<2, 3, 2>(p, max_slabs, ncu, st);

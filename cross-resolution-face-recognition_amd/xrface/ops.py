@@ -20,7 +20,8 @@ import os as _os
 _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
         "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2")),
         "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
-        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1"))}
+        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")),
+        "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0"))}
 
 
 def set_compute_dtype(dtype):
@@ -210,7 +211,13 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
     tgt = _direct(w)
     d64 = _wgrad64_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed)
     assert xform is None or d64, "on-load transform needs the direct 64-channel weight-gradient kernel"
-    rows = (not d64) and _wgrad_rows_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed)
+    rows_ok = _wgrad_rows_ok(x, dy, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed)
+    if d64 and xform is None and W > 64 and rows_ok and _cfg["wgrad_rows112"]:
+        # 112-wide maps without the on-load transform: the row-walking kernel's two-rows-per-step plan is faster in isolation (966 vs
+        # 822 TFLOP/s) and in the FHN step alone (C3 37.4 -> 36.4 ms), but its 145 KB workgroups cost the composed step more than
+        # they save beside the assistant's backward (C4 109.0 -> 110.0 ms): off by default (XR_WGRAD_ROWS112=1)
+        d64 = False
+    rows = (not d64) and rows_ok
     if d64:
         split = min(256, N * H)
     elif rows:
