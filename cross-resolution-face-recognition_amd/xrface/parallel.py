@@ -87,7 +87,7 @@ class BucketedAllReduce:
     signals more often than learned after its bucket has gone out makes ``finish()`` raise (and re-learn) instead of
     silently averaging incomplete gradients.  ``overlap=False`` defers every launch to ``finish()``."""
 
-    def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True):
+    def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True, force: bool = False):
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -115,7 +115,8 @@ class BucketedAllReduce:
         self._count = [0] * len(flat.params)
         self._late = None
         self.launch_order = []                     # bucket indices in the order they were launched this step (tests)
-        self.enabled = self.world > 1
+        # force: run the collectives even in a one-rank group (tests: the RCCL path on a single GPU)
+        self.enabled = self.world > 1 or (force and dist.is_initialized())
         if self.enabled and overlap:
             for i, p in enumerate(flat.params):
                 h = self._make_hook(i)

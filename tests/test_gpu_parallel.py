@@ -142,3 +142,91 @@ def test_bench_two_rank_rehearsal_prints_one_line():
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
     assert "cpu_baseline" not in line and "secondary" not in line      # rank-0-at-N=1 legs only
+
+
+@pytest.mark.timeout(300)
+def test_rccl_backend_single_rank_collectives():
+    """The RCCL transport the multi-GPU runs use (torch.distributed backend "nccl"), as far as ONE card can exercise it: a one-rank
+    process group initialised exactly as bench.py does (device_id, 127.0.0.1 rendezvous), the asynchronous ReduceOp.AVG all-reduce
+    of a flat gradient slice that BucketedAllReduce issues on this backend, a broadcast and a barrier.  (Two RCCL ranks cannot share a
+    GPU, so the multi-rank logic is covered over gloo above; this pins the library / op availability in the image.)"""
+    import subprocess
+    import sys
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl"
+g = torch.arange(1 << 20, dtype=torch.float32, device=dev)
+ref = g.clone()
+w = dist.all_reduce(g[1024:1 << 19], op=dist.ReduceOp.AVG, async_op=True)
+w.wait()
+dist.broadcast(g, 0)
+dist.barrier()
+torch.cuda.synchronize()
+assert torch.equal(g, ref), "AVG over one rank must be the identity"
+dist.destroy_process_group()
+print("rccl ok")
+''' % _free_port()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.timeout(600)
+def test_bucketed_allreduce_over_rccl_single_rank():
+    """BucketedAllReduce on the REAL backend of multi-GPU runs (RCCL, ReduceOp.AVG, asynchronous, launched from gradient hooks during
+    backward with the weight-gradient side stream on) in a one-rank group (force=True): three IR-SE-50 training steps run, buckets
+    go out from the hooks from the second step on, and the weights stay within the run-to-run spread of the same steps without a
+    reducer (an average over one rank is the identity; two identical reducer-less runs of this N = 4 train-mode-BatchNorm step
+    already differ by 1e-3 of max-abs after three steps -- fp32 atomics order -- so this is a smoke test of the transport, the
+    exactness of the overlap logic is what the two-rank test above pins)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="%d", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+import xrface
+from xrface import ops, parallel
+from xrface.loss.loss import CrossEntropyLoss
+from xrface.model.model_irse import IR_SE_50
+xrface.set_compute_dtype(torch.float32)
+assert ops._cfg["wgrad_stream"] == 1
+res = []
+for use in (True, False):
+    torch.manual_seed(5)
+    net = IR_SE_50([112, 112]).to(dev).train()
+    net.output_layer[1].p = 0.0
+    flat = parallel.FlatParams(net.parameters_in_execution_order())
+    opt = parallel.FusedSGD(flat, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    red = parallel.BucketedAllReduce(flat, bucket_mb=24.0, overlap=True, force=True) if use else None
+    g = torch.Generator(device=dev).manual_seed(3)
+    ce = CrossEntropyLoss()
+    early = []
+    for step in range(3):
+        x = torch.rand(4, 3, 112, 112, device=dev, generator=g) * 2 - 1
+        y = torch.randint(0, 512, (4,), device=dev, generator=g)
+        opt.zero_grad()
+        ce(net(x), y).backward()
+        if red is not None:
+            early.append(len(red.launch_order))
+            red.finish()
+        opt.step()
+    torch.cuda.synchronize()
+    res.append((flat.flat.clone(), early))
+(w1, early), (w0, _) = res
+assert red is None
+assert early[0] == 0 and early[1] > 0 and early[2] > 0, early          # step 0 learns the schedule, later steps overlap
+d = float((w1 - w0).abs().max() / w0.abs().max())
+assert d == d and d < 5e-3, d
+dist.destroy_process_group()
+print("rccl reducer ok", early, d)
+''' % (os.path.join(root, "cross-resolution-face-recognition_amd"), _free_port())
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0 and "rccl reducer ok" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])
