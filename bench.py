@@ -176,11 +176,15 @@ def cpu_baseline(dev, dtype, budget_s=12.0):
     # embedding parity of the benchmarked mode: eval-mode forward, HIP path (dtype) vs oracle (fp32 CPU)
     net.load_state_dict(sd)
     net.to(dev).eval()
-    xrface.set_compute_dtype(dtype)
     with torch.no_grad():
-        e_gpu = net(x.to(dev)).float().cpu()
         e_cpu, _ = R.ir_backbone(sd, x, se=True, train=False)
-    emb_err = float((e_gpu - e_cpu).norm(dim=1).max() / e_cpu.norm(dim=1).min())
+        errs = {}
+        for dtp in (dtype, torch.float32):      # the timed mode, and the fp32 parity mode (split-bf16 MFMA) the 1e-3 bar is met in
+            xrface.set_compute_dtype(dtp)
+            e_gpu = net(x.to(dev)).float().cpu()
+            errs[dtp] = float((e_gpu - e_cpu).norm(dim=1).max() / e_cpu.norm(dim=1).min())
+    xrface.set_compute_dtype(dtype)
+    emb_err = (errs[dtype], errs[torch.float32])
     del net
     R.teacher_step_grads(sd, x, t, se=True)  # warm-up
     steps, t0 = 0, time.perf_counter()
@@ -264,6 +268,26 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
                 "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
                 "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
     del fhn, flats, opts, res
+    torch.cuda.empty_cache()
+    # ---- C2 in the fp32 parity mode: the headline step in the mode that meets the 1e-3 embedding tolerance
+    xrface.set_compute_dtype(torch.float32)
+    from xrface.loss.loss import CrossEntropyLoss
+    net = model_irse.IR_SE_50([112, 112]).to(dev).train()
+    flat = parallel.FlatParams(net.parameters_in_execution_order())
+    opt = parallel.FusedSGD(flat, lr=0.05, momentum=0.9, weight_decay=5e-4)
+    xb, yb = synth_batch(256, dev, 14)
+    ce = CrossEntropyLoss()
+
+    def c2p():
+        opt.zero_grad()
+        ce(net(xb), yb).backward()
+        opt.step()
+    ms, _ = _timed(c2p, 1, 3)
+    out.append({"workload": "C2 in the fp32 parity mode (same step as the headline; every operand split into three bf16 planes, six "
+                            "plane-pair MFMAs per product: fp32-level accuracy -- the mode the 1e-3 parity tests run in)",
+                "per_gpu_batch": 256, "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 2),
+                "images_per_s": round(256 / ms * 1e3, 1)})
+    del net, flat, opt
     torch.cuda.empty_cache()
     # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case)
     xrface.set_compute_dtype(torch.float32)
@@ -445,7 +469,8 @@ def main():
             line["conv_ms_per_step_probed"] = round(sum(r["total_ms_per_step"] for r in table), 2)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], emb_err = cpu_baseline(dev, dtype)
-            line["embedding_rel_l2_vs_cpu"] = round(emb_err, 6)
+            line["embedding_rel_l2_vs_cpu"] = round(emb_err[0], 6)
+            line["embedding_rel_l2_vs_cpu_fp32_parity_mode"] = round(emb_err[1], 7)
         if world == 1 and not args.no_secondary and bf:
             del model, flat, opt, reducer
             torch.cuda.empty_cache()
