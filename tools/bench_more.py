@@ -10,7 +10,6 @@ from xrface import parallel, steps
 from xrface.graph import GraphedStep
 from xrface.model import FSRnet, model_irse, resnet
 from xrface.loss.loss import MSELossFunc
-from oracle import detgen as G
 
 dev = torch.device("cuda:0")
 
