@@ -188,6 +188,13 @@ class Backbone(Module):
         emb, tapped = self.f(enter(x), tuple(taps))
         return (leave2d(emb), *[leave(t) for t in tapped])
 
+    def lockstep_plan(self, taps=(2, 6, 20, 23)):
+        """(stages, tap positions, finish) for xrface.lockstep.run_lockstep: one stage per layer group of forward_taps."""
+        stages = [self.f_input] + [blk.f for blk in self.body] + [self.f_output]
+        tap_after = {i + 1 for i in taps}                       # stage index whose output is tapped (body block i = stage i + 1)
+        finish = lambda emb, tapped: (leave2d(emb), *[leave(t) for t in tapped])
+        return stages, tap_after, finish
+
     def _initialize_weights(self):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -203,61 +210,16 @@ class Backbone(Module):
                     m.bias.data.zero_()
 
 
-_LOCKSTEP = {}
-
-
 def forward_taps_lockstep(nets, xs, taps=(2, 6, 20, 23)):
-    """``[net.forward_taps(x, taps) for net, x in zip(nets, xs)]`` for INDEPENDENT backbones of the same depth (the student and the
-    assistant of the residual-KD step: different weights, the same sequence of layers), advanced block by block in lockstep, each on
-    its own stream.  A training step of one such network is a chain of MFMA-bound convolutions and HBM-bound normalisation passes
-    with nothing to overlap them with; two chains side by side let the convolutions of one run under the elementwise passes of the
-    other.  Because the autograd nodes are created alternately, the backward pass interleaves the same way (every node runs on the
-    stream of its forward).  The caller's stream waits for all of them before the outputs are used; after ``backward()`` it must
-    wait again (``lockstep_join``): a network that receives a detached input hands nothing back to the caller's stream."""
-    dev = xs[0].device
-    main = torch.cuda.current_stream(dev)
-    # the chains get the CALLER's stream priority: with a higher one, the chain that hands nothing back to the caller (the
-    # assistant) would outrank the work that follows on the caller's stream (the FHN backward) -- measured +10 % on C4
-    prio = getattr(main, "priority", 0)
-    key = (dev.index, len(nets))
-    if key not in _LOCKSTEP or _LOCKSTEP[key][0] != prio:
-        _LOCKSTEP[key] = (prio, [torch.cuda.Stream(dev, priority=prio) for _ in nets])
-    streams = _LOCKSTEP[key][1]
-    depth = len(nets[0].body)
-    assert all(len(n.body) == depth for n in nets), "lockstep needs backbones of equal depth"
-    # stale weight packs are refreshed by ONE launch for every registered parameter (ops._PackPlan): it must run on the caller's
-    # stream BEFORE the fork -- triggered lazily by the first convolution of one chain it would rewrite the other chain's packs
-    # on a stream the other chain does not wait for
-    if ops._cfg["pack_plan"]:
-        ops._pack_plan.refresh()
-    for s in streams:
-        s.wait_stream(main)
-    taps = tuple(taps)
-    with batched_bn_counters(list(nets)):
-        ys, tapped = [None] * len(nets), [[] for _ in nets]
-        for j, (n, x, s) in enumerate(zip(nets, xs, streams)):
-            with torch.cuda.stream(s):
-                ys[j] = n.f_input(enter(x))
-        for i in range(depth):
-            for j, (n, s) in enumerate(zip(nets, streams)):
-                with torch.cuda.stream(s):
-                    ys[j] = n.body[i].f(ys[j])
-                    if i in taps:
-                        tapped[j].append(ys[j])
-        outs = []
-        for j, (n, s) in enumerate(zip(nets, streams)):
-            with torch.cuda.stream(s):
-                outs.append((leave2d(n.f_output(ys[j])), *[leave(t) for t in tapped[j]]))
-    for s in streams:
-        main.wait_stream(s)
-    return outs
+    """``[net.forward_taps(x, taps) for net, x in zip(nets, xs)]`` for independent backbones of the same depth (the student and
+    the assistant of the residual-KD step), advanced block by block in lockstep on their own streams: see xrface/lockstep.py."""
+    from ..lockstep import run_lockstep
+    return run_lockstep(nets, xs, [n.lockstep_plan(taps) for n in nets])
 
 
 def lockstep_join(device, n):
-    """The caller's stream waits for the lockstep streams (call after backward(), before the optimizers read the gradients)."""
-    main = torch.cuda.current_stream(device)
-    for s in _LOCKSTEP.get((device.index, n), (0, ()))[1]:
-        main.wait_stream(s)
+    from ..lockstep import join
+    join(device, n)
 
 
 class TeacherWithTaps(Module):

@@ -108,6 +108,18 @@ class ResNet(Module):
         z, feats = self.f(enter(x))
         return (leave2d(z), *[leave(t) for t in feats])
 
+    def lockstep_plan(self):
+        """(stages, tap positions, finish) for xrface.lockstep.run_lockstep: stem, every residual block, head; the four stage
+        outputs are tapped (the 5-tuple forward returns)."""
+        stages = [lambda buf: xnn.conv_bn(self.conv1, self.bn1, buf, act="relu")]
+        tap_after = set()
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            stages += [blk.f for blk in layer]
+            tap_after.add(len(stages) - 1)
+        stages.append(lambda y: self.bn_o2.f(self.fc.f(self.bn_o1.f(y))))
+        finish = lambda z, feats: (leave2d(z), *[leave(t) for t in feats])
+        return stages, tap_after, finish
+
 
 def ResNet_34(input_size=[112, 112]):
     return ResNet(input_size, BasicBlock, [3, 4, 6, 3])

@@ -192,13 +192,25 @@ def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_op
     assistant.train()
     with torch.no_grad():
         t = teacher.forward_taps(x, taps) if hasattr(teacher, "forward_taps") else teacher(x)
-    s = student(x)
-    a = assistant(x)
+    lock = False
+    if ops._cfg["lockstep"] and x.is_cuda and not ops._graph["capturing"] and hasattr(student, "lockstep_plan") \
+            and hasattr(assistant, "lockstep_plan") and type(student) is type(assistant):
+        from . import lockstep
+        plans = [student.lockstep_plan(), assistant.lockstep_plan()]
+        lock = lockstep.plans_compatible(plans)
+    if lock:
+        # student and assistant are independent (both see x): stage by stage in lockstep on their own streams (xrface/lockstep.py)
+        s, a = lockstep.run_lockstep((student, assistant), (x, x), plans)
+    else:
+        s = student(x)
+        a = assistant(x)
     s_loss = crit(s[0], t[0])
     a_loss = crit(t[1] - s[1], a[1]) + crit(t[2] - s[2], a[2]) + crit(t[3] - s[3], a[3]) + crit(t[4] - s[4], a[4]) \
         + crit(t[0] - s[0], a[0])
     _pair_grads(s_loss, student, retain=True)
     _pair_grads(a_loss, assistant, retain=False)
+    if lock:
+        lockstep.join(x.device, 2)
     if student_optimizer is not None:
         student_optimizer.step()
     if assistant_optimizer is not None:
