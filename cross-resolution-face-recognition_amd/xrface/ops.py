@@ -520,6 +520,17 @@ def _bias_grad(dy, K):
     return sums[0, 0, :K]
 
 
+_IDENT = {}
+
+
+def _ident_coefs(n, device):
+    """[n][64] ones / zeros (the identity transform for the direct kernel's backward-reduction epilogue), cached per batch size."""
+    key = (n, device.index)
+    if key not in _IDENT:
+        _IDENT[key] = (torch.ones((n, 64), dtype=torch.float32, device=device), torch.zeros((n, 64), dtype=torch.float32, device=device))
+    return _IDENT[key]
+
+
 class _Conv2d(Function):
     """aten::conv2d replacement (weight [K][C][R][S] fp32 Parameter; x NHWC buffer)."""
 
@@ -624,9 +635,18 @@ class _Conv2d(Function):
                     dpass = dpass.to(x.dtype)
             add_in_kernel = dpass is not None and red is None and C % 8 == 0
             pe = _probe_begin(("dgrad", Cp, K, H, W, R, stride))
-            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
-                              kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red),
-                              ptr(dpass) if add_in_kernel else None, stream())
+            if red is not None and dpass is None and direct64_ok(x, w, stride, pad) and Kp == 64:
+                # 64 -> 64 3x3 (conv1 of the IR stage-1 blocks, model_irse.py:56-59): the direct kernel with the BatchNorm-backward
+                # sums in its epilogue -- sum d and sum d * x per image (identity transform: scale 1, shift 0, no slope), folded over
+                # the batch by xr_norm_bwd_coeffs like the spread partials of the implicit GEMM
+                red = zeros_f32((3, N, C), x.device)
+                one, zero = _ident_coefs(N, x.device)
+                lib.xr_conv64_direct_bwdred(ptr(dy), ptr(pk), ptr(dx), N, H, W, 1, ptr(link.x), ptr(one), ptr(zero), None, ptr(red),
+                                            stream())
+            else:
+                lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
+                                  kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red),
+                                  ptr(dpass) if add_in_kernel else None, stream())
             if pe is not None:
                 pe.record()
             if dpass is not None and not add_in_kernel:
