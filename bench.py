@@ -269,6 +269,42 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
                 "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
     del fhn, flats, opts, res
     torch.cuda.empty_cache()
+    # ---- SR-variant generators + perceptual (IR-50 feature) losses, train_FHN.py:251-308.  4 x depth-4 bottleneck
+    # hourglass prior = 475 convolutions of 64 channels: thousands of small launches -> eager is host-bound; one HIP graph replay
+    from xrface.graph import GraphedStep
+    from xrface.model import FSRnet_sr
+    nsr = 32
+    nets = {"coarse": FSRnet_sr.Coarse_SR_Network().to(dev), "encoder": FSRnet_sr.Fine_SR_Encoder().to(dev),
+            "prior": FSRnet_sr.Prior_Estimation_Network().to(dev), "decoder": FSRnet_sr.Fine_SR_Decoder().to(dev)}
+    bb = model_irse.IR_50([112, 112]).to(dev).eval()
+    for p_ in bb.parameters():
+        p_.requires_grad_(False)
+    flats = {"coarse": parallel.FlatParams(nets["coarse"].parameters()), "prior": parallel.FlatParams(nets["prior"].parameters()),
+             "encdec": parallel.FlatParams(list(nets["encoder"].parameters()) + list(nets["decoder"].parameters()))}
+    opts = {k: parallel.FusedAdam(f, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5) for k, f in flats.items()}
+    hrs, _ = synth_batch(nsr, dev, 15)
+    lrs = synth_lr(hrs)
+    hms = torch.rand(nsr, 112, 112, device=dev)
+    pars = torch.randint(0, 13, (nsr, 1, 112, 112), device=dev)
+    lbuf = torch.zeros(3, device=dev)
+
+    def sr_step(lr_, hr_, hm_, par_):
+        for o in opts.values():
+            o.zero_grad()
+        l_, _ = steps.fhn_perceptual_step(nets, bb, lr_, hr_, hm_, par_, optimizers=opts)
+        lbuf.copy_(torch.stack([l_["coarse"].float(), l_["prior"].float(), l_["encdec"].float()]))
+        return lbuf
+    ms_e, _ = _timed(lambda: sr_step(lrs, hrs, hms, pars), 2, 3)
+    gs = GraphedStep(sr_step, [lrs, hrs, hms, pars], warmup=2)
+    ms_g, _ = _timed(lambda: gs(lrs, hrs, hms, pars), 2, 5)
+    gs.close()
+    sr_gf = 3 * 131.434 + 5 * IRSE50_FWD_GFLOP      # three trainable generators + prior, IR-50 forward x3 and input gradient x2
+    out.append({"workload": "SURVEY 8f-1/2: SR-variant FHN (coarse / encoder / bottleneck-hourglass prior / decoder) + perceptual IR-50 "
+                            "feature losses (train_FHN.py:251-308), Adam x3; eager launches vs one HIP-graph replay per step",
+                "per_gpu_batch": nsr, "dtype": "bf16", "ms_per_step_eager": round(ms_e, 1), "ms_per_step": round(ms_g, 1),
+                "images_per_s": round(nsr / ms_g * 1e3, 1), "achieved_tflops": round(sr_gf * nsr / ms_g, 1)})
+    del nets, bb, flats, opts, gs
+    torch.cuda.empty_cache()
     # ---- C2 in the fp32 parity mode: the headline step in the mode that meets the 1e-3 embedding tolerance
     xrface.set_compute_dtype(torch.float32)
     from xrface.loss.loss import CrossEntropyLoss

@@ -297,3 +297,49 @@ def test_eval_coefficients_follow_running_statistics_in_eager_mode():
     ref = torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.1, bn.eps)
     assert _rel(y1, ref) < 1e-5
     assert _rel(y1, y0) > 1e-2
+
+
+def test_graphed_sr_perceptual_step_replays_and_trains():
+    """SURVEY 8f-1/2 as one HIP graph: the SR-variant perceptual-loss step (train_FHN.py:251-308; per-pair gradients through
+    torch.autograd.grad, three fused Adam updates) captured once and replayed -- the first replay reproduces an eager step from
+    the same weights, and replays on a fixed batch reduce the generator losses."""
+    import copy
+    import xrface
+    from xrface import parallel, steps
+    from xrface.graph import GraphedStep
+    from xrface.model import FSRnet_sr as M, model_irse
+
+    xrface.set_compute_dtype(torch.bfloat16)
+    try:
+        torch.manual_seed(4)
+        n = 2
+        nets = {"coarse": M.Coarse_SR_Network().to(DEV), "encoder": M.Fine_SR_Encoder().to(DEV),
+                "prior": M.Prior_Estimation_Network().to(DEV), "decoder": M.Fine_SR_Decoder().to(DEV)}
+        bb = model_irse.IR_50([112, 112]).to(DEV).eval()
+        for p_ in bb.parameters():
+            p_.requires_grad_(False)
+        flats = {"coarse": parallel.FlatParams(nets["coarse"].parameters()), "prior": parallel.FlatParams(nets["prior"].parameters()),
+                 "encdec": parallel.FlatParams(list(nets["encoder"].parameters()) + list(nets["decoder"].parameters()))}
+        opts = {k: parallel.FusedAdam(f, lr=2e-4, betas=(0.5, 0.999)) for k, f in flats.items()}
+        hr = _faces(n, 3)
+        lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 7), size=(112, 112), mode="bilinear").contiguous()
+        hm = torch.rand(n, 112, 112, device=DEV)
+        par = torch.randint(0, 13, (n, 1, 112, 112), device=DEV)
+        lbuf = torch.zeros(3, device=DEV)
+
+        def step(lr_, hr_, hm_, par_):
+            for o in opts.values():
+                o.zero_grad()
+            l_, _ = steps.fhn_perceptual_step(nets, bb, lr_, hr_, hm_, par_, optimizers=opts)
+            lbuf.copy_(torch.stack([l_["coarse"].float(), l_["prior"].float(), l_["encdec"].float()]))
+            return lbuf
+
+        gs = GraphedStep(step, [lr, hr, hm, par], warmup=2)
+        first = gs(lr, hr, hm, par).clone()
+        for _ in range(8):
+            last = gs(lr, hr, hm, par).clone()
+        assert torch.isfinite(first).all() and torch.isfinite(last).all()
+        assert float(last[0]) < float(first[0]) and float(last[2]) < float(first[2]), (first.tolist(), last.tolist())
+        gs.close()
+    finally:
+        xrface.set_compute_dtype(torch.float32)
