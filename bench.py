@@ -226,145 +226,174 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
     xrface.set_compute_dtype(torch.bfloat16)
     mk_fhn = lambda: {"coarse": FSRnet.Course_SR_Network().to(dev), "prior": FSRnet.Prior_Estimation_Network().to(dev),
                       "encoder": FSRnet.Fine_SR_Encoder().to(dev), "decoder": FSRnet.Fine_SR_Decoder().to(dev)}
-    # ---- C4: the north-star composed step
-    torch.manual_seed(0)
-    fhn = mk_fhn()
-    student, assistant = model_irse.IR_SE_50([112, 112]).to(dev), model_irse.IR_SE_50([112, 112]).to(dev)
-    teacher = model_irse.IR_SE_50([112, 112]).to(dev).eval()
-    for p_ in teacher.parameters():
-        p_.requires_grad_(False)
-    fhn_params = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]
-    flats = [parallel.FlatParams(fhn_params), parallel.FlatParams(student.parameters_in_execution_order()),
-             parallel.FlatParams(assistant.parameters_in_execution_order())]
-    opts = [parallel.FusedRMSprop(flats[0], lr=1e-5, alpha=0.99, weight_decay=1e-5),
-            parallel.FusedRMSprop(flats[1], lr=1e-4, alpha=0.99, weight_decay=1e-5),
-            parallel.FusedRMSprop(flats[2], lr=1e-4, alpha=0.99, weight_decay=1e-5)]
-    hr, _ = synth_batch(c4_batch, dev, 11)
-    lr = synth_lr(hr)
-    ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts), 2, 5)
-    (sl, al), _ = res
-    tf = C4_STEP_GFLOP * c4_batch / ms            # GFLOP per ms = TFLOP/s
-    out.append({"workload": "C4 (BASELINE configs[3], per-GPU shape): root FHN (trainable) -> IR-SE-50 student + assistant vs frozen "
-                            "IR-SE-50 teacher on hr, residual-KD MSE losses, RMSprop x3, Dropout on, 112x112",
-                "per_gpu_batch": c4_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c4_batch / ms * 1e3, 1),
-                "algorithmic_tflop_per_step": round(C4_STEP_GFLOP * c4_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
-                "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "student_loss": round(float(sl), 5),
-                "assistant_loss": round(float(al), 5)})
-    del fhn, student, assistant, teacher, flats, opts, res
-    torch.cuda.empty_cache()
-    # ---- C3: full FHN step (per-network gradients from one backward pass), landmark + parsing losses
-    fhn = mk_fhn()
-    flats = {k: parallel.FlatParams(fhn[k].parameters()) for k in fhn}
-    opts = {k: parallel.FusedRMSprop(flats[k], lr=1e-5, alpha=0.99, weight_decay=1e-5) for k in fhn}
-    hr, _ = synth_batch(c3_batch, dev, 12)
-    lr = synth_lr(hr)
-    hm = torch.rand(c3_batch, 28, 28, device=dev)
-    par = torch.randint(0, 11, (c3_batch, 1, 28, 28), device=dev)
-    ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts), 2, 5)
-    tf = 3.0 * FHN_FWD_GFLOP * c3_batch / ms
-    out.append({"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
-                            "parsing losses, per-network gradients, RMSprop x4",
-                "per_gpu_batch": c3_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c3_batch / ms * 1e3, 1),
-                "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
-                "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
-    del fhn, flats, opts, res
-    torch.cuda.empty_cache()
-    # ---- SR-variant generators + perceptual (IR-50 feature) losses, train_FHN.py:251-308.  4 x depth-4 bottleneck
-    # hourglass prior = 475 convolutions of 64 channels: thousands of small launches -> eager is host-bound; one HIP graph replay
-    from xrface.graph import GraphedStep
-    from xrface.model import FSRnet_sr
-    nsr = 32
-    nets = {"coarse": FSRnet_sr.Coarse_SR_Network().to(dev), "encoder": FSRnet_sr.Fine_SR_Encoder().to(dev),
-            "prior": FSRnet_sr.Prior_Estimation_Network().to(dev), "decoder": FSRnet_sr.Fine_SR_Decoder().to(dev)}
-    bb = model_irse.IR_50([112, 112]).to(dev).eval()
-    for p_ in bb.parameters():
-        p_.requires_grad_(False)
-    flats = {"coarse": parallel.FlatParams(nets["coarse"].parameters()), "prior": parallel.FlatParams(nets["prior"].parameters()),
-             "encdec": parallel.FlatParams(list(nets["encoder"].parameters()) + list(nets["decoder"].parameters()))}
-    opts = {k: parallel.FusedAdam(f, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5) for k, f in flats.items()}
-    hrs, _ = synth_batch(nsr, dev, 15)
-    lrs = synth_lr(hrs)
-    hms = torch.rand(nsr, 112, 112, device=dev)
-    pars = torch.randint(0, 13, (nsr, 1, 112, 112), device=dev)
-    lbuf = torch.zeros(3, device=dev)
+    # Every workload runs in its own function under try / except: a failure in one of them (e.g. a graph capture) is reported
+    # in its entry and can never cost the headline line.
+    work = []
 
-    def sr_step(lr_, hr_, hm_, par_):
-        for o in opts.values():
-            o.zero_grad()
-        l_, _ = steps.fhn_perceptual_step(nets, bb, lr_, hr_, hm_, par_, optimizers=opts)
-        lbuf.copy_(torch.stack([l_["coarse"].float(), l_["prior"].float(), l_["encdec"].float()]))
-        return lbuf
-    ms_e, _ = _timed(lambda: sr_step(lrs, hrs, hms, pars), 2, 3)
-    gs = GraphedStep(sr_step, [lrs, hrs, hms, pars], warmup=2)
-    ms_g, _ = _timed(lambda: gs(lrs, hrs, hms, pars), 2, 5)
-    gs.close()
-    sr_gf = 3 * 131.434 + 5 * IRSE50_FWD_GFLOP      # three trainable generators + prior, IR-50 forward x3 and input gradient x2
-    out.append({"workload": "SURVEY 8f-1/2: SR-variant FHN (coarse / encoder / bottleneck-hourglass prior / decoder) + perceptual IR-50 "
-                            "feature losses (train_FHN.py:251-308), Adam x3; eager launches vs one HIP-graph replay per step",
-                "per_gpu_batch": nsr, "dtype": "bf16", "ms_per_step_eager": round(ms_e, 1), "ms_per_step": round(ms_g, 1),
-                "images_per_s": round(nsr / ms_g * 1e3, 1), "achieved_tflops": round(sr_gf * nsr / ms_g, 1)})
-    del nets, bb, flats, opts, gs
-    torch.cuda.empty_cache()
-    # ---- C2 in the fp32 parity mode: the headline step in the mode that meets the 1e-3 embedding tolerance
-    xrface.set_compute_dtype(torch.float32)
-    from xrface.loss.loss import CrossEntropyLoss
-    net = model_irse.IR_SE_50([112, 112]).to(dev).train()
-    flat = parallel.FlatParams(net.parameters_in_execution_order())
-    opt = parallel.FusedSGD(flat, lr=0.05, momentum=0.9, weight_decay=5e-4)
-    xb, yb = synth_batch(256, dev, 14)
-    ce = CrossEntropyLoss()
+    def w_c4():
+        # ---- C4: the north-star composed step
+        torch.manual_seed(0)
+        fhn = mk_fhn()
+        student, assistant = model_irse.IR_SE_50([112, 112]).to(dev), model_irse.IR_SE_50([112, 112]).to(dev)
+        teacher = model_irse.IR_SE_50([112, 112]).to(dev).eval()
+        for p_ in teacher.parameters():
+            p_.requires_grad_(False)
+        fhn_params = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]
+        flats = [parallel.FlatParams(fhn_params), parallel.FlatParams(student.parameters_in_execution_order()),
+                 parallel.FlatParams(assistant.parameters_in_execution_order())]
+        opts = [parallel.FusedRMSprop(flats[0], lr=1e-5, alpha=0.99, weight_decay=1e-5),
+                parallel.FusedRMSprop(flats[1], lr=1e-4, alpha=0.99, weight_decay=1e-5),
+                parallel.FusedRMSprop(flats[2], lr=1e-4, alpha=0.99, weight_decay=1e-5)]
+        hr, _ = synth_batch(c4_batch, dev, 11)
+        lr = synth_lr(hr)
+        ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts), 2, 5)
+        (sl, al), _ = res
+        tf = C4_STEP_GFLOP * c4_batch / ms            # GFLOP per ms = TFLOP/s
+        out.append({"workload": "C4 (BASELINE configs[3], per-GPU shape): root FHN (trainable) -> IR-SE-50 student + assistant vs frozen "
+                                "IR-SE-50 teacher on hr, residual-KD MSE losses, RMSprop x3, Dropout on, 112x112",
+                    "per_gpu_batch": c4_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c4_batch / ms * 1e3, 1),
+                    "algorithmic_tflop_per_step": round(C4_STEP_GFLOP * c4_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
+                    "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "student_loss": round(float(sl), 5),
+                    "assistant_loss": round(float(al), 5)})
+        del fhn, student, assistant, teacher, flats, opts, res
+        torch.cuda.empty_cache()
+    work.append(("C4", w_c4))
 
-    def c2p():
-        opt.zero_grad()
-        ce(net(xb), yb).backward()
-        opt.step()
-    ms, _ = _timed(c2p, 1, 3)
-    out.append({"workload": "C2 in the fp32 parity mode (same step as the headline; every operand split into three bf16 planes, six "
-                            "plane-pair MFMAs per product: fp32-level accuracy -- the mode the 1e-3 parity tests run in)",
-                "per_gpu_batch": 256, "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 2),
-                "images_per_s": round(256 / ms * 1e3, 1)})
-    del net, flat, opt
-    torch.cuda.empty_cache()
-    # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case)
-    xrface.set_compute_dtype(torch.float32)
-    net = FSRnet.Course_SR_Network().to(dev)
-    opt = torch.optim.RMSprop(net.parameters(), lr=1e-4, alpha=0.99, weight_decay=1e-5)
-    hr4, _ = synth_batch(4, dev, 13)
-    lr4 = synth_lr(hr4)
-    crit = MSELossFunc()
+    def w_c3():
+        # ---- C3: full FHN step (per-network gradients from one backward pass), landmark + parsing losses
+        fhn = mk_fhn()
+        flats = {k: parallel.FlatParams(fhn[k].parameters()) for k in fhn}
+        opts = {k: parallel.FusedRMSprop(flats[k], lr=1e-5, alpha=0.99, weight_decay=1e-5) for k in fhn}
+        hr, _ = synth_batch(c3_batch, dev, 12)
+        lr = synth_lr(hr)
+        hm = torch.rand(c3_batch, 28, 28, device=dev)
+        par = torch.randint(0, 11, (c3_batch, 1, 28, 28), device=dev)
+        ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts), 2, 5)
+        tf = 3.0 * FHN_FWD_GFLOP * c3_batch / ms
+        out.append({"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
+                                "parsing losses, per-network gradients, RMSprop x4",
+                    "per_gpu_batch": c3_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c3_batch / ms * 1e3, 1),
+                    "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
+                    "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
+        del fhn, flats, opts, res
+        torch.cuda.empty_cache()
+    work.append(("C3", w_c3))
 
-    def c1():
-        opt.zero_grad(set_to_none=True)
-        _, img = net(lr4)
-        (12.0 * crit(img, hr4)).backward()
-        opt.step()
-    ms, _ = _timed(c1, 3, 10)
-    out.append({"workload": "C1 (BASELINE configs[0]): Course_SR_Network fwd+bwd of 12*mse97 + RMSprop", "per_gpu_batch": 4,
-                "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 3), "images_per_s": round(4 / ms * 1e3, 1)})
-    del net, opt
-    xrface.set_compute_dtype(torch.bfloat16)
-    # ---- C5: P = 1e6 pair distances + 4000-threshold / 10-fold ROC
-    P = 1_000_000
-    g = torch.Generator(device=dev)
-    g.manual_seed(0)
-    e1 = torch.randn(P, 512, device=dev, generator=g)
-    same = torch.rand(P, device=dev, generator=g) < 0.5
-    e2 = torch.where(same[:, None], e1 + 0.5 * torch.randn(P, 512, device=dev, generator=g), torch.randn(P, 512, device=dev, generator=g))
-    ms, _ = _timed(lambda: pair_dist(e1, e2), 2, 8)
-    gbs = P * (2 * 512 * 4 + 4) / ms / 1e6
-    fold = np.random.RandomState(0).randint(0, 10, P).astype(np.int32)
-    same_h = same.cpu().numpy()
-    thr = np.arange(0, 12000, 3)
-    calculate_roc(thr, e1, e2, same_h, nrof_folds=10, fold_id=fold)
-    t0 = time.perf_counter()
-    _, _, acc, _ = calculate_roc(thr, e1, e2, same_h, nrof_folds=10, fold_id=fold)
-    torch.cuda.synchronize()
-    roc_ms = (time.perf_counter() - t0) * 1e3
-    out.append({"workload": "C5 (BASELINE configs[4]): 1M-pair 512-d squared-L2 distances + 4000-threshold / 10-fold ROC",
-                "pairs": P, "pairdist_ms": round(ms, 3), "pairdist_gb_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
-                "calculate_roc_ms": round(roc_ms, 2), "accuracy": round(float(acc), 4)})
+    def w_sr_perceptual_step():
+        # ---- SR-variant generators + perceptual (IR-50 feature) losses, train_FHN.py:251-308.  4 x depth-4 bottleneck
+        # hourglass prior = 475 convolutions of 64 channels: thousands of small launches -> eager is host-bound; one HIP graph replay
+        from xrface.graph import GraphedStep
+        from xrface.model import FSRnet_sr
+        nsr = 32
+        nets = {"coarse": FSRnet_sr.Coarse_SR_Network().to(dev), "encoder": FSRnet_sr.Fine_SR_Encoder().to(dev),
+                "prior": FSRnet_sr.Prior_Estimation_Network().to(dev), "decoder": FSRnet_sr.Fine_SR_Decoder().to(dev)}
+        bb = model_irse.IR_50([112, 112]).to(dev).eval()
+        for p_ in bb.parameters():
+            p_.requires_grad_(False)
+        flats = {"coarse": parallel.FlatParams(nets["coarse"].parameters()), "prior": parallel.FlatParams(nets["prior"].parameters()),
+                 "encdec": parallel.FlatParams(list(nets["encoder"].parameters()) + list(nets["decoder"].parameters()))}
+        opts = {k: parallel.FusedAdam(f, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5) for k, f in flats.items()}
+        hrs, _ = synth_batch(nsr, dev, 15)
+        lrs = synth_lr(hrs)
+        hms = torch.rand(nsr, 112, 112, device=dev)
+        pars = torch.randint(0, 13, (nsr, 1, 112, 112), device=dev)
+        lbuf = torch.zeros(3, device=dev)
+
+        def sr_step(lr_, hr_, hm_, par_):
+            for o in opts.values():
+                o.zero_grad()
+            l_, _ = steps.fhn_perceptual_step(nets, bb, lr_, hr_, hm_, par_, optimizers=opts)
+            lbuf.copy_(torch.stack([l_["coarse"].float(), l_["prior"].float(), l_["encdec"].float()]))
+            return lbuf
+        ms_e, _ = _timed(lambda: sr_step(lrs, hrs, hms, pars), 2, 3)
+        gs = GraphedStep(sr_step, [lrs, hrs, hms, pars], warmup=2)
+        ms_g, _ = _timed(lambda: gs(lrs, hrs, hms, pars), 2, 5)
+        gs.close()
+        sr_gf = 3 * 131.434 + 5 * IRSE50_FWD_GFLOP      # three trainable generators + prior, IR-50 forward x3 and input gradient x2
+        out.append({"workload": "SURVEY 8f-1/2: SR-variant FHN (coarse / encoder / bottleneck-hourglass prior / decoder) + perceptual IR-50 "
+                                "feature losses (train_FHN.py:251-308), Adam x3; eager launches vs one HIP-graph replay per step",
+                    "per_gpu_batch": nsr, "dtype": "bf16", "ms_per_step_eager": round(ms_e, 1), "ms_per_step": round(ms_g, 1),
+                    "images_per_s": round(nsr / ms_g * 1e3, 1), "achieved_tflops": round(sr_gf * nsr / ms_g, 1)})
+        del nets, bb, flats, opts, gs
+        torch.cuda.empty_cache()
+    work.append(("SR perceptual step", w_sr_perceptual_step))
+
+    def w_c2_parity_mode():
+        # ---- C2 in the fp32 parity mode: the headline step in the mode that meets the 1e-3 embedding tolerance
+        xrface.set_compute_dtype(torch.float32)
+        from xrface.loss.loss import CrossEntropyLoss
+        net = model_irse.IR_SE_50([112, 112]).to(dev).train()
+        flat = parallel.FlatParams(net.parameters_in_execution_order())
+        opt = parallel.FusedSGD(flat, lr=0.05, momentum=0.9, weight_decay=5e-4)
+        xb, yb = synth_batch(256, dev, 14)
+        ce = CrossEntropyLoss()
+
+        def c2p():
+            opt.zero_grad()
+            ce(net(xb), yb).backward()
+            opt.step()
+        ms, _ = _timed(c2p, 1, 3)
+        out.append({"workload": "C2 in the fp32 parity mode (same step as the headline; every operand split into three bf16 planes, six "
+                                "plane-pair MFMAs per product: fp32-level accuracy -- the mode the 1e-3 parity tests run in)",
+                    "per_gpu_batch": 256, "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 2),
+                    "images_per_s": round(256 / ms * 1e3, 1)})
+        del net, flat, opt
+        torch.cuda.empty_cache()
+    work.append(("C2 parity mode", w_c2_parity_mode))
+
+    def w_c1():
+        # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case)
+        xrface.set_compute_dtype(torch.float32)
+        net = FSRnet.Course_SR_Network().to(dev)
+        opt = torch.optim.RMSprop(net.parameters(), lr=1e-4, alpha=0.99, weight_decay=1e-5)
+        hr4, _ = synth_batch(4, dev, 13)
+        lr4 = synth_lr(hr4)
+        crit = MSELossFunc()
+
+        def c1():
+            opt.zero_grad(set_to_none=True)
+            _, img = net(lr4)
+            (12.0 * crit(img, hr4)).backward()
+            opt.step()
+        ms, _ = _timed(c1, 3, 10)
+        out.append({"workload": "C1 (BASELINE configs[0]): Course_SR_Network fwd+bwd of 12*mse97 + RMSprop", "per_gpu_batch": 4,
+                    "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 3), "images_per_s": round(4 / ms * 1e3, 1)})
+        del net, opt
+        xrface.set_compute_dtype(torch.bfloat16)
+    work.append(("C1", w_c1))
+
+    def w_c5():
+        # ---- C5: P = 1e6 pair distances + 4000-threshold / 10-fold ROC
+        P = 1_000_000
+        g = torch.Generator(device=dev)
+        g.manual_seed(0)
+        e1 = torch.randn(P, 512, device=dev, generator=g)
+        same = torch.rand(P, device=dev, generator=g) < 0.5
+        e2 = torch.where(same[:, None], e1 + 0.5 * torch.randn(P, 512, device=dev, generator=g), torch.randn(P, 512, device=dev, generator=g))
+        ms, _ = _timed(lambda: pair_dist(e1, e2), 2, 8)
+        gbs = P * (2 * 512 * 4 + 4) / ms / 1e6
+        fold = np.random.RandomState(0).randint(0, 10, P).astype(np.int32)
+        same_h = same.cpu().numpy()
+        thr = np.arange(0, 12000, 3)
+        calculate_roc(thr, e1, e2, same_h, nrof_folds=10, fold_id=fold)
+        t0 = time.perf_counter()
+        _, _, acc, _ = calculate_roc(thr, e1, e2, same_h, nrof_folds=10, fold_id=fold)
+        torch.cuda.synchronize()
+        roc_ms = (time.perf_counter() - t0) * 1e3
+        out.append({"workload": "C5 (BASELINE configs[4]): 1M-pair 512-d squared-L2 distances + 4000-threshold / 10-fold ROC",
+                    "pairs": P, "pairdist_ms": round(ms, 3), "pairdist_gb_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+                    "calculate_roc_ms": round(roc_ms, 2), "accuracy": round(float(acc), 4)})
+    work.append(("C5", w_c5))
+
+    for name, fn in work:
+        try:
+            fn()
+        except Exception as e:   # noqa: BLE001 -- report, restore the mode, go on
+            out.append({"workload": name, "error": f"{type(e).__name__}: {e}"[:300]})
+        finally:
+            xrface.set_compute_dtype(torch.bfloat16)
+            torch.cuda.empty_cache()
     return out
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -510,9 +539,12 @@ def main():
         if world == 1 and not args.no_secondary and bf:
             del model, flat, opt, reducer
             torch.cuda.empty_cache()
-            with torch.cuda.stream(hp):      # same stream set-up as the headline: the side work yields to the critical path
-                line["secondary"] = secondary_workloads(dev)
-            torch.cuda.current_stream(dev).wait_stream(hp)
+            try:
+                with torch.cuda.stream(hp):      # same stream set-up as the headline: the side work yields to the critical path
+                    line["secondary"] = secondary_workloads(dev)
+                torch.cuda.current_stream(dev).wait_stream(hp)
+            except Exception as e:   # noqa: BLE001 -- the headline line is printed whatever happens to the extras
+                line["secondary"] = [{"error": f"{type(e).__name__}: {e}"[:300]}]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
