@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 N, H = (int(v) for v in os.environ.get("SHAPE", "128,112").split(","))
 x = torch.randn(N, H, H, 64, device=dev).bfloat16()
 dy = torch.randn(N, H, H, 64, device=dev).bfloat16()
+x2 = torch.randn(N, H, H, 64, device=dev).bfloat16()
 w = torch.randn(64, 64, 3, 3, device=dev) * 0.05
 y = torch.empty_like(x)
 pk, _ = ops._packed(w, "fwd", torch.bfloat16, 64, 1, 9, 64, 64, 576, 0, 1, 9)
@@ -25,6 +26,7 @@ for _ in range(int(os.environ.get("REPS", 3))):
     lib.xr_conv64_direct(ptr(dy), ptr(pkd), None, ptr(y), N, H, H, 1, None, None, None, None, None, stream())                  # dgrad
     lib.xr_conv64_direct(ptr(dy), ptr(pkd), None, ptr(y), N, H, H, 1, None, None, None, None, ptr(x), stream())                # dgrad + add
     lib.xr_conv64_direct_bwdred(ptr(dy), ptr(pkd), ptr(y), N, H, H, 1, ptr(x), ptr(sc), ptr(sh), ptr(al), ptr(red), stream())  # dgrad + IN-bwd sums
+    lib.xr_conv64_direct_tailred(ptr(dy), ptr(pkd), ptr(y), N, H, H, 1, ptr(x), ptr(x2), ptr(x), ptr(sc), ptr(sh), ptr(al), ptr(red), stream())  # chained tail
     lib.xr_conv64_wgrad(ptr(x), ptr(dy), ptr(slabs), N, H, H, 256, None, None, None, stream())
     lib.xr_conv64_wgrad(ptr(x), ptr(dy), ptr(slabs), N, H, H, 256, ptr(sc), ptr(sh), ptr(al), stream())
 torch.cuda.synchronize()

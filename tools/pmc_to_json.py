@@ -11,6 +11,7 @@ ORDER = {"a": ["fwd conv3x3 256->256 @14x14 s1", "dgrad conv3x3 256->256 @14x14 
          "b": ["fwd conv3x3 64->64 @112x112 s1 (+stats)", "fwd conv3x3 64->64 @112x112 s1 (+IN/PReLU on load, +stats)",
                "dgrad conv3x3 64->64 @112x112 s1", "dgrad conv3x3 64->64 @112x112 s1 (+residual add)",
                "dgrad conv3x3 64->64 @112x112 s1 (+InstanceNorm-backward sums)",
+               "dgrad conv3x3 64->64 @112x112 s1 (+residual add, chained tail: prelu' and sums of the previous block)",
                "wgrad conv3x3 64->64 @112x112 s1", "wgrad conv3x3 64->64 @112x112 s1 (+IN/PReLU on load)"]}
 FLOP = {"a": 2.0 * 256 * 14 * 14 * 256 * 256 * 9, "b": 2.0 * 128 * 112 * 112 * 64 * 64 * 9}
 ALG_BYTES = {"a": {"fwd": 2 * 256 * 196 * 256 * 2 + 256 * 2304 * 2, "dgrad": 2 * 256 * 196 * 256 * 2 + 256 * 2304 * 2,
