@@ -276,6 +276,10 @@ ROWS_CASES = [  # N, C, K, H, W, stride
     (5, 64, 128, 28, 28, 2),     # stride 2, RS = 6 over images of 14 output rows
     (70, 64, 64, 16, 20, 1),     # more steps than one pass: ragged last step, runs that start mid-image
     (9, 64, 64, 32, 24, 2),      # stride 2, ragged widths (12 output columns in a 16-column plan)
+    (4, 64, 64, 7, 7, 1),        # the 7 x 7 maps (not routed here by default: 7 of 16 MFMA pixels used), two images per step
+    (4, 128, 64, 14, 14, 2),     # stride 2 down to 7 x 7
+    (2, 64, 128, 9, 13, 1),      # odd sizes: 13-pixel rows, staging groups that are not a multiple of 64 chunks
+    (1, 64, 64, 3, 8, 1),        # fewer rows than one step
 ]
 
 
