@@ -9,6 +9,7 @@ section 0).  Pinned semantics: evaluate every forward once
   c4_step       BASELINE configs[3]: FHN -> IR-SE-50 student + assistant vs frozen IR-SE-50 teacher, residual-KD losses
   kd_step       distill_main.py:59-74 (the second student_optimizer.step() at :74 is a reference bug; the
                 assistant is stepped)
+  verify_step   distill_main.py:111-138: pair verification of one batch (teacher alone, student + assistant summed)
   teacher_step  train_teacher_model.py:189-202
 """
 from __future__ import annotations
@@ -279,3 +280,25 @@ def teacher_step(model, x, target, optimizer=None, criterion=None):
     if optimizer is not None:
         optimizer.step()
     return loss.detach(), out.detach()
+
+
+def verify_step(teacher, student, assistant, img1, img2, label, thresholds=None, nrof_folds=10, fold_id=None):
+    """distill_main.py:111-138 for one batch of pairs: the teacher's embeddings of (img1, img2) go through calculate_roc; the
+    student's and the assistant's embeddings are SUMMED (the assistant learned the teacher-minus-student residual) and go
+    through it too.  Everything stays on the device (embeddings, distances, histogram, K-fold sweep); ``label``: same / different
+    per pair.  ``fold_id`` pins the K-fold membership (the reference draws it from an unseeded KFold).
+    Returns ((tpr, fpr, accuracy, best_thresholds) of the teacher, the same of student + assistant)."""
+    import numpy as np
+    from .utils.utils import calculate_roc
+    thresholds = np.arange(0, 12000, 3) if thresholds is None else thresholds
+    for m in (teacher, student, assistant):
+        m.eval()
+    first = lambda out: out[0] if isinstance(out, (tuple, list)) else out
+    lab = np.asarray(label.cpu() if isinstance(label, torch.Tensor) else label)
+    with torch.no_grad():
+        t1, t2 = first(teacher(img1)), first(teacher(img2))
+        t_res = calculate_roc(thresholds, t1, t2, lab, nrof_folds=nrof_folds, pca=0, fold_id=fold_id)
+        s1 = first(student(img1)) + first(assistant(img1))
+        s2 = first(student(img2)) + first(assistant(img2))
+        s_res = calculate_roc(thresholds, s1, s2, lab, nrof_folds=nrof_folds, pca=0, fold_id=fold_id)
+    return t_res, s_res

@@ -759,3 +759,37 @@ def test_overall_network_gan_224_matches_reference_fixture():
         outs = net(lr[:2].to(DEV), hr[:2].to(DEV))
     for nm, t in zip(("sr", "coarse", "landmark", "parsing", "emb1", "emb2"), outs):
         check_against(st, "eval/" + nm, t, TOL)
+
+
+def test_verify_step_matches_host_evaluation_of_the_same_embeddings():
+    """steps.verify_step (distill_main.py:111-138: teacher alone, student + assistant summed, calculate_roc on each) against the
+    oracle's calculate_roc fed with the very embeddings the HIP path produced: same tpr / fpr / accuracy / thresholds (the networks
+    themselves are pinned by the KD fixture; this pins the wiring of the evaluation caller)."""
+    import xrface
+    from xrface.model import model_irse, resnet
+    from xrface.steps import verify_step
+    xrface.set_compute_dtype(torch.float32)
+    teacher, _ = load_det(model_irse.IR_50([112, 112]), 0)
+    student, _ = load_det(resnet.ResNet_34(), 1)
+    assistant, _ = load_det(resnet.ResNet_34(), 2)
+    P = 24
+    img1 = G.synth_faces(P, 112, seed=1, start=900).to(DEV)
+    img2 = torch.where((torch.arange(P) % 2 == 0)[:, None, None, None], G.synth_faces(P, 112, seed=1, start=900) * 0.97 + 0.01,
+                       G.synth_faces(P, 112, seed=1, start=1300)).to(DEV)
+    label = (torch.arange(P) % 2 == 0).numpy()
+    fold = (np.arange(P) * 7 % 10).astype(np.int32)
+    thresholds = np.arange(0, 40000, 10)
+    (t_tpr, t_fpr, t_acc, t_best), (s_tpr, s_fpr, s_acc, s_best) = verify_step(teacher, student, assistant, img1, img2, label,
+                                                                              thresholds=thresholds, nrof_folds=10, fold_id=fold)
+    folds = [(np.where(fold != f)[0], np.where(fold == f)[0]) for f in range(10)]
+    with torch.no_grad():
+        for m in (teacher, student, assistant):
+            m.eval()
+        t1, t2 = teacher(img1), teacher(img2)
+        s1, s2 = student(img1)[0] + assistant(img1)[0], student(img2)[0] + assistant(img2)[0]
+    for got, (e1, e2) in (((t_tpr, t_fpr, t_acc, t_best), (t1, t2)), ((s_tpr, s_fpr, s_acc, s_best), (s1, s2))):
+        r_tpr, r_fpr, r_acc, r_best = R.calculate_roc(thresholds, e1.float().cpu().numpy(), e2.float().cpu().numpy(), label, folds)
+        # distances: HIP kernel vs numpy differ in the last bits -> a pair may cross one threshold of the grid
+        assert np.abs(got[0] - r_tpr).max() <= 1.0 / (P // 2) + 1e-9 and np.abs(got[1] - r_fpr).max() <= 1.0 / (P // 2) + 1e-9
+        assert abs(got[2] - r_acc) <= 0.5 / P * 10 + 1e-9 and np.abs(got[3] - r_best).max() <= 10 * 2
+    assert 0.0 <= t_acc <= 1.0 and 0.0 <= s_acc <= 1.0
