@@ -1584,6 +1584,11 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
   const bool wide = K > 64 && g_tune[3] == 0;
   if (dtype == XR_BF16) {
     if (wide) return transposed ? launch_igemm<0, 128, 128, 2, true>(p, st) : launch_igemm<0, 128, 128, 2, false>(p, st);
+    // <= 32 output columns (the 64 -> 3 image heads of FSRNet, model/FSRnet.py:326,455; 1x1 parsing head): a 128 x 32 tile --
+    // the narrow-tile kernel is instruction-issue bound, and half of a 64-column tile's weight staging / MFMAs / epilogue
+    // would be spent on padding
+    if (K <= 32 && g_tune[15] == 0)
+      return transposed ? launch_igemm<0, 128, 32, 4, true>(p, st) : launch_igemm<0, 128, 32, 4, false>(p, st);
     return transposed ? launch_igemm<0, 128, 64, 4, true>(p, st) : launch_igemm<0, 128, 64, 4, false>(p, st);
   }
   if (wide) return transposed ? launch_igemm<1, 128, 128, 2, true>(p, st) : launch_igemm<1, 128, 128, 2, false>(p, st);
