@@ -342,23 +342,33 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
     work.append(("C2 parity mode", w_c2_parity_mode))
 
     def w_c1():
-        # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case)
+        # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case); eager launches and one HIP-graph replay
+        from xrface.graph import GraphedStep
         xrface.set_compute_dtype(torch.float32)
         net = FSRnet.Course_SR_Network().to(dev)
-        opt = torch.optim.RMSprop(net.parameters(), lr=1e-4, alpha=0.99, weight_decay=1e-5)
+        flat = parallel.FlatParams(net.parameters())
+        opt = parallel.FusedRMSprop(flat, lr=1e-4, alpha=0.99, weight_decay=1e-5)
         hr4, _ = synth_batch(4, dev, 13)
         lr4 = synth_lr(hr4)
         crit = MSELossFunc()
+        lbuf = torch.zeros((), device=dev)
 
-        def c1():
-            opt.zero_grad(set_to_none=True)
-            _, img = net(lr4)
-            (12.0 * crit(img, hr4)).backward()
+        def c1(lr_, hr_):
+            opt.zero_grad()
+            _, img = net(lr_)
+            loss = 12.0 * crit(img, hr_)
+            loss.backward()
             opt.step()
-        ms, _ = _timed(c1, 3, 10)
-        out.append({"workload": "C1 (BASELINE configs[0]): Course_SR_Network fwd+bwd of 12*mse97 + RMSprop", "per_gpu_batch": 4,
-                    "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step": round(ms, 3), "images_per_s": round(4 / ms * 1e3, 1)})
-        del net, opt
+            lbuf.copy_(loss.detach())
+            return lbuf
+        ms, _ = _timed(lambda: c1(lr4, hr4), 3, 10)
+        gs = GraphedStep(c1, [lr4, hr4], warmup=2)
+        ms_g, _ = _timed(lambda: gs(lr4, hr4), 3, 20)
+        gs.close()
+        out.append({"workload": "C1 (BASELINE configs[0]): Course_SR_Network fwd+bwd of 12*mse97 + RMSprop; eager launches vs one HIP-graph "
+                                "replay per step", "per_gpu_batch": 4, "dtype": "fp32 (split-bf16 MFMA)", "ms_per_step_eager": round(ms, 3),
+                    "ms_per_step": round(ms_g, 3), "images_per_s": round(4 / ms_g * 1e3, 1)})
+        del net, opt, flat, gs
         xrface.set_compute_dtype(torch.bfloat16)
     work.append(("C1", w_c1))
 
