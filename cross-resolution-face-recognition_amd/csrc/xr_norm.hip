@@ -239,38 +239,60 @@ struct AffP {
   void* y; const void* dy; float* red; const float* coef; void* dx; void* dres;
   int coef_per_group;  // scale/shift are [G][C] (1) or [C] (0)
   const void* dx_add;  // optional: added to dx (gradient arriving through an identity branch of the same input)
+  // fused second reduction of the backward apply (xr_affine_act_bwd_apply_red): red2[0][g][c] += sum dx, red2[1][g][c] +=
+  // sum dx * y2 over the rows of group g; with bcast the coefficients are per channel and shared by all groups
+  const void* y2; float* red2; int bcast;
 };
 
-template <typename T>
+template <typename T> __device__ __forceinline__ float as_stored(float v);   // the value a later pass reads back
+template <> __device__ __forceinline__ float as_stored<bf16_t>(float v) { return bf2f(f2bf(v)); }
+template <> __device__ __forceinline__ float as_stored<float>(float v) { return v; }
+
+// STATS: also sum the (stored) outputs and their squares per (group, channel) into p.red[2][G][C] -- the statistics pass
+// of a BatchNorm that reads y next (xr_affine_act_stats)
+template <typename T, bool STATS>
 __global__ __launch_bounds__(NT) void affine_act_kernel(AffP p, Geo geo) {
+  extern __shared__ float lds[];
   const int t = threadIdx.x;
-  if (t >= geo.active) return;
+  const bool active = t < geo.active;
+  if (!STATS && !active) return;
   const int cch = t % geo.cpr, rsub = t / geo.cpr;
   const int g = blockIdx.y;
   const int r_begin = blockIdx.x * geo.rows_per_block;
   int r_end = r_begin + geo.rows_per_block;
   if (r_end > geo.rows) r_end = geo.rows;
-  const int ci = (p.coef_per_group ? g * geo.C : 0) + cch * 8;
-  float sc[8], sh[8], al[8];
-  load_coef8(p.scale, ci, sc, 1.f);
-  load_coef8(p.shift, ci, sh, 0.f);
-  load_coef8(p.alpha, cch * 8, al, 0.f);
-  const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
-  const T* x = reinterpret_cast<const T*>(p.x) + gbase;
-  const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
-  T* y = reinterpret_cast<T*>(p.y) + gbase;
-  for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
-    float v[8], rv[8], o[8];
-    ld8(x + (size_t)r * geo.C, v);
-    if (res) ld8(res + (size_t)r * geo.C, rv);
+  float acc[2][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float z = v[e] * sc[e] + sh[e];
-      if (res) z += rv[e];
-      o[e] = act_fwd(z, al[e], p.act);
+  for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = 0.f;
+  if (active) {
+    const int ci = (p.coef_per_group ? g * geo.C : 0) + cch * 8;
+    float sc[8], sh[8], al[8];
+    load_coef8(p.scale, ci, sc, 1.f);
+    load_coef8(p.shift, ci, sh, 0.f);
+    load_coef8(p.alpha, cch * 8, al, 0.f);
+    const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
+    const T* x = reinterpret_cast<const T*>(p.x) + gbase;
+    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
+    T* y = reinterpret_cast<T*>(p.y) + gbase;
+    for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+      float v[8], rv[8], o[8];
+      ld8(x + (size_t)r * geo.C, v);
+      if (res) ld8(res + (size_t)r * geo.C, rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = v[e] * sc[e] + sh[e];
+        if (res) z += rv[e];
+        o[e] = act_fwd(z, al[e], p.act);
+        if constexpr (STATS) {
+          const float q = as_stored<T>(o[e]);
+          acc[0][e] += q;
+          acc[1][e] += q * q;
+        }
+      }
+      st8(y + (size_t)r * geo.C, o);
     }
-    st8(y + (size_t)r * geo.C, o);
   }
+  if constexpr (STATS) block_reduce_atomic<2>(acc, p.red, geo.G, g, geo.C, geo.cpr, cch, rsub, geo.rpb, active, lds);
 }
 
 template <typename T>
@@ -419,54 +441,72 @@ __global__ void reduce_groups_kernel(const float* __restrict__ red, float* __res
   }
 }
 
-template <typename T>
+// RED2: the rows of a group are one image; besides writing dx the kernel sums (dx, dx * y2) per (image, channel) into
+// p.red2[2][G][C] -- the backward reduction of the block tail that produced this norm's input (xr_affine_act_bwd_apply_red)
+template <typename T, bool RED2>
 __global__ __launch_bounds__(NT) void affine_act_bwd_apply_kernel(AffP p, Geo geo) {
+  extern __shared__ float lds[];
   const int t = threadIdx.x;
-  if (t >= geo.active) return;
+  const bool active = t < geo.active;
+  if (!RED2 && !active) return;
   const int cch = t % geo.cpr, rsub = t / geo.cpr;
   const int g = blockIdx.y;
   const int r_begin = blockIdx.x * geo.rows_per_block;
   int r_end = r_begin + geo.rows_per_block;
   if (r_end > geo.rows) r_end = geo.rows;
-  const int ci = (p.coef_per_group ? g * geo.C : 0) + cch * 8;
-  float sc[8], sh[8], al[8], cA[8], cB[8], cC[8];
-  load_coef8(p.scale, ci, sc, 1.f);
-  load_coef8(p.shift, ci, sh, 0.f);
-  load_coef8(p.alpha, cch * 8, al, 0.f);
-  const size_t GC = (size_t)geo.G * geo.C;
-  if (p.coef) {
-    ld8(p.coef + (size_t)g * geo.C + cch * 8, cA);
-    ld8(p.coef + GC + (size_t)g * geo.C + cch * 8, cB);
-    ld8(p.coef + 2 * GC + (size_t)g * geo.C + cch * 8, cC);
-  } else {
+  float acc[2][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { cA[e] = sc[e]; cB[e] = 0.f; cC[e] = 0.f; }
-  }
-  const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
-  const T* x = reinterpret_cast<const T*>(p.x) + gbase;
-  const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
-  const T* dy = reinterpret_cast<const T*>(p.dy) + gbase;
-  T* dx = p.dx ? reinterpret_cast<T*>(p.dx) + gbase : nullptr;
-  T* dres = p.dres ? reinterpret_cast<T*>(p.dres) + gbase : nullptr;
-  const T* dxa = p.dx_add ? reinterpret_cast<const T*>(p.dx_add) + gbase : nullptr;
-  for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
-    float v[8], rv[8], d[8], o[8], dzv[8], ex[8];
-    ld8(x + (size_t)r * geo.C, v);
-    ld8(dy + (size_t)r * geo.C, d);
-    if (res) ld8(res + (size_t)r * geo.C, rv);
-    if (dxa) ld8(dxa + (size_t)r * geo.C, ex);
+  for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = 0.f;
+  if (active) {
+    const int gc = p.bcast ? 0 : g * geo.C;
+    const int ci = (p.coef_per_group ? gc : 0) + cch * 8;
+    float sc[8], sh[8], al[8], cA[8], cB[8], cC[8];
+    load_coef8(p.scale, ci, sc, 1.f);
+    load_coef8(p.shift, ci, sh, 0.f);
+    load_coef8(p.alpha, cch * 8, al, 0.f);
+    const size_t GC = p.bcast ? (size_t)geo.C : (size_t)geo.G * geo.C;
+    if (p.coef) {
+      ld8(p.coef + (size_t)gc + cch * 8, cA);
+      ld8(p.coef + GC + (size_t)gc + cch * 8, cB);
+      ld8(p.coef + 2 * GC + (size_t)gc + cch * 8, cC);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float z = v[e] * sc[e] + sh[e];
-      if (res) z += rv[e];
-      const float dz = d[e] * act_grad(z, al[e], p.act);
-      dzv[e] = dz;
-      o[e] = cA[e] * dz + cB[e] * v[e] + cC[e];
-      if (dxa) o[e] += ex[e];
+      for (int e = 0; e < 8; ++e) { cA[e] = sc[e]; cB[e] = 0.f; cC[e] = 0.f; }
     }
-    if (dx) st8(dx + (size_t)r * geo.C, o);
-    if (dres) st8(dres + (size_t)r * geo.C, dzv);
+    const size_t gbase = ((size_t)g * geo.rows) * geo.C + cch * 8;
+    const T* x = reinterpret_cast<const T*>(p.x) + gbase;
+    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
+    const T* dy = reinterpret_cast<const T*>(p.dy) + gbase;
+    T* dx = p.dx ? reinterpret_cast<T*>(p.dx) + gbase : nullptr;
+    T* dres = p.dres ? reinterpret_cast<T*>(p.dres) + gbase : nullptr;
+    const T* dxa = p.dx_add ? reinterpret_cast<const T*>(p.dx_add) + gbase : nullptr;
+    const T* y2 = RED2 ? reinterpret_cast<const T*>(p.y2) + gbase : nullptr;
+    for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
+      float v[8], rv[8], d[8], o[8], dzv[8], ex[8], w[8];
+      ld8(x + (size_t)r * geo.C, v);
+      ld8(dy + (size_t)r * geo.C, d);
+      if (res) ld8(res + (size_t)r * geo.C, rv);
+      if (dxa) ld8(dxa + (size_t)r * geo.C, ex);
+      if constexpr (RED2) ld8(y2 + (size_t)r * geo.C, w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = v[e] * sc[e] + sh[e];
+        if (res) z += rv[e];
+        const float dz = d[e] * act_grad(z, al[e], p.act);
+        dzv[e] = dz;
+        o[e] = cA[e] * dz + cB[e] * v[e] + cC[e];
+        if (dxa) o[e] += ex[e];
+        if constexpr (RED2) {
+          const float q = as_stored<T>(o[e]);
+          acc[0][e] += q;
+          acc[1][e] += q * w[e];
+        }
+      }
+      if (dx) st8(dx + (size_t)r * geo.C, o);
+      if (dres) st8(dres + (size_t)r * geo.C, dzv);
+    }
   }
+  if constexpr (RED2) block_reduce_atomic<2>(acc, p.red2, geo.G, g, geo.C, geo.cpr, cch, rsub, geo.rpb, active, lds);
 }
 
 // --------------------------------------------------------------------------------------------- SE excitation
@@ -758,8 +798,22 @@ extern "C" int xr_affine_act(int dtype, const void* x, const float* scale, const
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, y, nullptr, nullptr, nullptr, nullptr, nullptr, coef_per_group, nullptr};
   Geo geo = make_geo(G, rows, C, 4096);
-  if (dtype == XR_BF16) return launch_aff<bf16_t>(affine_act_kernel<bf16_t>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
-  return launch_aff<float>(affine_act_kernel<float>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
+  if (dtype == XR_BF16) return launch_aff<bf16_t>(affine_act_kernel<bf16_t, false>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
+  return launch_aff<float>(affine_act_kernel<float, false>, p, geo, 0, (hipStream_t)stream, "xr_affine_act");
+}
+
+extern "C" int xr_affine_act_stats(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                   const float* alpha, int act, void* y, float* stats, int G, int rows, int C,
+                                   int coef_per_group, void* stream) {
+  if (int e = check_geo("xr_affine_act_stats", dtype, G, rows, C)) return e;
+  XR_CHECK_ARG(x && y && stats, "xr_affine_act_stats: null pointer");
+  XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_stats: PReLU needs alpha");
+  AffP p{x, scale, shift, res, alpha, act, y, nullptr, stats, nullptr, nullptr, nullptr, coef_per_group, nullptr};
+  Geo geo = make_geo(G, rows, C, g_tune[8]);
+  const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
+  if (dtype == XR_BF16)
+    return launch_aff<bf16_t>(affine_act_kernel<bf16_t, true>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_stats");
+  return launch_aff<float>(affine_act_kernel<float, true>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_stats");
 }
 
 extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* scale, const float* shift, const void* res,
@@ -809,8 +863,24 @@ extern "C" int xr_affine_act_bwd_apply(int dtype, const void* x, const float* sc
   AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, dres, coef_per_group, dx_add};
   Geo geo = make_geo(G, rows, C, 4096);
   if (dtype == XR_BF16)
-    return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
-  return launch_aff<float>(affine_act_bwd_apply_kernel<float>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
+    return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t, false>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
+  return launch_aff<float>(affine_act_bwd_apply_kernel<float, false>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
+}
+
+extern "C" int xr_affine_act_bwd_apply_red(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                           const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
+                                           int G, int rows, int C, const void* dx_add, const void* y2, float* red2,
+                                           void* stream) {
+  if (int e = check_geo("xr_affine_act_bwd_apply_red", dtype, G, rows, C)) return e;
+  XR_CHECK_ARG(x && dy && dx && y2 && red2, "xr_affine_act_bwd_apply_red: null pointer");
+  XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_apply_red: PReLU needs alpha");
+  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, dres, 1, dx_add, y2, red2, 1};
+  Geo geo = make_geo(G, rows, C, 2 * g_tune[9]);   // five streams per row: wants twice the blocks of the plain reduce (tools/norm_bench.py)
+  const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
+  if (dtype == XR_BF16)
+    return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t, true>, p, geo, smem, (hipStream_t)stream,
+                              "xr_affine_act_bwd_apply_red");
+  return launch_aff<float>(affine_act_bwd_apply_kernel<float, true>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_apply_red");
 }
 
 extern "C" int xr_se_excite_fwd(const float* pooled_sum, const float* w1, const float* w2, float* hidden, float* s, int N,

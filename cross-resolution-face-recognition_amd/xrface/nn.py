@@ -152,7 +152,7 @@ class _BNMixin:
         self._count()
         mom = self._momentum()
         return ops.norm_act_pass(buf, self.weight, self.bias, self.running_mean, self.running_var, "bn", None, training, mom,
-                                 self.eps, link if training else None)
+                                 self.eps, link if training else None, ops.chain_of(buf))
 
 
 class BatchNorm2d(_BNMixin, nn.BatchNorm2d):

@@ -20,7 +20,7 @@ import os as _os
 _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
         "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2")),
         "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
-        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")),
+        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")),
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0"))}
 
 
@@ -900,11 +900,12 @@ class _NormAct(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False, link=None,
-                slink=None, eval_coef=None):
+                slink=None, eval_coef=None, tail=None):
         x = _c(x)
         N, H, W, C = x.shape
         ctx.passthrough = passthrough
         ctx.link = link   # see BnLink: the consumer convolution's dgrad may deliver this norm's backward reductions
+        ctx.tail = tail   # see TailLink: this norm's backward apply may take the backward sums of the unit that produced x
         if link is not None:
             link.x = x    # the exact buffer the statistics were taken over
         if res is not None:
@@ -1037,10 +1038,19 @@ class _NormAct(Function):
                     dgamma = _emit_small(p_g, (red[1, 0] - rmean * red[0, 0]) * torch.rsqrt(rvar + eps))
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[5]) else None
-        if dx is not None or dres is not None:
+        tail = ctx.tail
+        if (tail is not None and dx is not None and dres is None and mode == "bn" and G == 1 and _cfg["chain_units"]
+                and tail.y is not None and tail.y.shape == x.shape and tail.y.dtype == x.dtype):
+            # dx IS the gradient entering the tail of the unit before this norm: take that tail's per-image sums here
+            n_img = x.shape[0]
+            red2 = zeros_f32((2, n_img, C), x.device)
+            lib.xr_affine_act_bwd_apply_red(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
+                                            None, n_img, rows // n_img, C, ptr(dpass), ptr(tail.y), ptr(red2), stream())
+            tail.deliver(dx, red2)
+        elif dx is not None or dres is not None:
             lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
                                         ptr(dres), G, rows, C, 1, ptr(dpass), stream())
-        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None, None, None
 
 
 class BnLink:
@@ -1067,11 +1077,43 @@ class BnLink:
         return red
 
 
+class TailLink:
+    """Couples the fused tail of one IR-SE unit (out = SE(BN(y)) + shortcut, _BnSeAdd) with the BatchNorm that opens the next
+    unit.  Forward: the tail's elementwise pass also sums out / out^2 (``slink``), so the next norm skips its statistics pass.
+    Backward: the next norm's apply pass writes dx = the gradient entering the tail, and sums (dx, dx * y) per image while it does
+    (xr_affine_act_bwd_apply_red), so the tail skips its reduction pass.  Both sides only trust a delivery keyed to exactly the
+    tensor they receive: an extra consumer of the unit output (a feature tap) makes autograd sum gradients into a new tensor
+    and the tail falls back to its own pass."""
+
+    def __init__(self):
+        self.y = None         # the tail's input buffer (set by its forward)
+        self.slink = None     # StatsLink carrying the statistics of the unit output
+        self.red = None
+        self.key = None
+
+    def deliver(self, dx, red):
+        self.red, self.key = red, (dx.data_ptr(), dx._version, tuple(dx.shape))
+
+    def take(self, dout):
+        red, key = self.red, self.key
+        self.red = self.key = None
+        if red is None or dout is None or key != (dout.data_ptr(), dout._version, tuple(dout.shape)):
+            return None
+        return red
+
+
+def chain_of(x):
+    """The TailLink a unit tail attached to its output (None when x is anything else)."""
+    return getattr(x, "_xr_tail", None) if _cfg["chain_units"] else None
+
+
 def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", act=None, training=True, momentum=0.1, eps=EPS,
-                  link=None):
+                  link=None, tail=None):
     """(norm(x), x'): x' aliases x; route identity branches (block shortcuts) through x' and the two gradients of x are
     summed inside the norm's backward apply kernel instead of by a separate elementwise pass."""
-    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, True, link)
+    slink = tail.slink if tail is not None else None
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, True, link, slink, None,
+                          tail if training else None)
 
 
 def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,
@@ -1493,10 +1535,11 @@ class _BnSeAdd(Function):
     then a single elementwise pass out = y*(a*s) + (b*s) + shortcut.  Backward is one reduction pass + one apply pass."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, rmean, rvar, w1, w2, shortcut, training, momentum, eps):
+    def forward(ctx, y, gamma, beta, rmean, rvar, w1, w2, shortcut, training, momentum, eps, tail=None):
         y = _c(y)
         N, H, W, C = y.shape
         HW, Cr = H * W, w1.shape[0]
+        ctx.tail = tail
         dev = y.device
         f32 = dict(dtype=torch.float32, device=dev)
         sums_n = zeros_f32((2, N, C), dev)
@@ -1525,7 +1568,15 @@ class _BnSeAdd(Function):
                         Cr, HW, stream())
         sc = None if shortcut is None else _c(shortcut)
         out = torch.empty_like(y)
-        lib.xr_affine_act(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), N, HW, C, 1, stream())
+        if tail is not None:   # the statistics of `out` ride along for the BatchNorm that opens the next unit
+            tail.y = y
+            osum = zeros_f32((2, N, C), dev)
+            lib.xr_affine_act_stats(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), ptr(osum), N, HW, C, 1,
+                                    stream())
+            tail.slink = StatsLink()
+            tail.slink.deliver(out, osum)
+        else:
+            lib.xr_affine_act(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), N, HW, C, 1, stream())
         ctx.save_for_backward(y, sums_n, a, b, mean, invstd, gm, w1f, w2f, pooled, hidden, s)
         ctx.meta = (training, shortcut is not None)
         ctx.prefs = (gamma, beta, w1, w2)
@@ -1543,8 +1594,10 @@ class _BnSeAdd(Function):
         HW, Cr = H * W, hidden.shape[1]
         dev = y.device
         f32 = dict(dtype=torch.float32, device=dev)
-        red = zeros_f32((3, N, C), dev)  # red[0] = S1 = sum dout, red[1] = S2 = sum dout*y   (per image)
-        lib.xr_affine_act_bwd_reduce(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(red), N, HW, C, 1, stream())
+        red = ctx.tail.take(dout) if ctx.tail is not None else None   # delivered by the next unit's BatchNorm backward
+        if red is None:
+            red = zeros_f32((3, N, C), dev)  # red[0] = S1 = sum dout, red[1] = S2 = sum dout*y   (per image)
+            lib.xr_affine_act_bwd_reduce(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(red), N, HW, C, 1, stream())
         dpre2, dhid, dp = torch.empty((N, C), **f32), torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
         coef = torch.empty((3, N, C), **f32)
         t_g, t_b = _direct(p_g), _direct(p_b)
@@ -1584,7 +1637,7 @@ class _BnSeAdd(Function):
             if t2 is not None:
                 dw2 = None
                 _direct_done(w2)
-        return dy, dgamma, dbeta, None, None, dw1, dw2, (dout if has_sc else None), None, None, None
+        return dy, dgamma, dbeta, None, None, dw1, dw2, (dout if has_sc else None), None, None, None, None
 
 
 def bn_se_add(y, bn, se, shortcut):
@@ -1592,8 +1645,13 @@ def bn_se_add(y, bn, se, shortcut):
     training = bn.training or not bn.track_running_stats
     bn._count()
     mom = bn._momentum()
-    return _BnSeAdd.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, se.fc1.weight, se.fc2.weight, shortcut, training,
-                          mom, bn.eps)
+    # a training unit offers its output to the next unit's opening BatchNorm through a TailLink (picked up by chain_of)
+    tail = TailLink() if (training and _cfg["chain_units"] and torch.is_grad_enabled() and y.requires_grad) else None
+    out = _BnSeAdd.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, se.fc1.weight, se.fc2.weight, shortcut, training,
+                         mom, bn.eps, tail)
+    if tail is not None:
+        out._xr_tail = tail
+    return out
 
 
 # ------------------------------------------------------------------------------------------------- resampling

@@ -206,6 +206,14 @@ int xr_affine_act(int dtype, const void* x, const float* scale, const float* shi
                   const float* alpha, int act, void* y, int G, int rows, int C, int coef_per_group, void* stream);
 /* coef_per_group: scale/shift are [G][C] (1) or shared [C] (0) */
 
+/* The same pass that also takes the statistics of its OUTPUT: stats[0][g][c] += sum y, stats[1][g][c] += sum y*y over the rows
+ * of group g (y as stored, i.e. rounded to bf16; [2][G][C] fp32 zeroed by the caller).  When y is the block output that the next
+ * block's training-mode BatchNorm normalises (model_irse.py:56-66 -> :76-91 of the next unit) that norm's xr_group_stats pass
+ * disappears: xr_norm_finalize(fold = G) folds the per-group sums. */
+int xr_affine_act_stats(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                        const float* alpha, int act, void* y, float* stats, int G, int rows, int C, int coef_per_group,
+                        void* stream);
+
 /* Backward, pass 1:  z = x*scale+shift+res ; dz = dy*act'(z)
  *   red[0][g][c] += sum dz ; red[1][g][c] += sum dz*x ; red[2][g][c] += sum dy*z*[z<=0]  (PReLU dalpha)
  * (3*G*C floats, caller zeroes). */
@@ -228,6 +236,16 @@ int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const 
                             int G, int rows, int C, int coef_per_group, const void* dx_add, void* stream);
 /* dx_add (optional, laid out like x): added to dx -- the gradient arriving through an identity branch of the same
  * input (block shortcut), so autograd's separate summation pass disappears. */
+
+/* Pass 2 of a BatchNorm that OPENS a residual unit, chained with pass 1 of the unit before it (model_irse.py:76-91): the G
+ * groups are the images (rows = H*W), scale / shift / coef are per channel ([C], [3][C]: one statistics group spanning the
+ * batch), and while dx -- which is the gradient dout entering the previous unit's tail out = SE(BN(y2)) + shortcut -- streams
+ * out, the kernel accumulates
+ *   red2[0][g][c] += sum dx,   red2[1][g][c] += sum dx * y2        (dx as stored; [2][G][C] fp32 zeroed by the caller)
+ * = S1, S2 of xr_bnse_bwd, so that tail's xr_affine_act_bwd_reduce pass over (dout, y2) disappears.  y2 is laid out like x. */
+int xr_affine_act_bwd_apply_red(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                const float* alpha, int act, const void* dy, const float* coef, void* dx, void* dres,
+                                int G, int rows, int C, const void* dx_add, const void* y2, float* red2, void* stream);
 /* out[v][c] (+)= sum_g red[v][g][c], v < NV.  BatchNorm statistics / backward sums are taken per image
  * (G = N: at most a few blocks contend on one atomic address) and folded over the batch here. */
 int xr_reduce_groups(const float* red, float* out, int NV, int G, int C, int accumulate, void* stream);

@@ -618,6 +618,70 @@ def test_bn_backward_reduction_fused_into_conv_dgrad(cin, depth, stride, hw, dty
         xrface.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("c0,c1,stride,hw,n", [(64, 64, 1, 20, 8), (64, 128, 2, 28, 6), (256, 256, 1, 14, 32), (256, 512, 2, 14, 5)])
+def test_chained_ir_se_units_share_statistics_and_backward_sums(c0, c1, stride, hw, n, dtype):
+    """Two bottleneck_IR_SE units in a row (model_irse.py:69-91).  With ops.TailLink the first unit's tail pass also takes the
+    statistics of its output (xr_affine_act_stats: the second unit's opening BatchNorm skips its statistics pass) and that
+    BatchNorm's backward apply also takes the first tail's per-image sums (xr_affine_act_bwd_apply_red: the tail skips its reduce
+    pass).  Same outputs, running statistics, input gradient and parameter gradients as the unchained passes; both links must
+    really fire; an extra consumer of the unit output (a feature tap) must make the tail fall back to its own pass."""
+    import copy
+    import xrface
+    from xrface import ops
+    from xrface.model.model_irse import bottleneck_IR_SE
+    from xrface.ops import enter, leave
+    xrface.set_compute_dtype(dtype)
+    orig_take, orig_stake = ops.TailLink.take, ops.StatsLink.take
+    try:
+        torch.manual_seed(11)
+        u0 = [bottleneck_IR_SE(c0, c0, 1).to(DEV).train(), bottleneck_IR_SE(c0, c1, stride).to(DEV).train()]
+        x0 = rnd(f"chain{c0}{c1}", n, c0, hw, hw)
+        fired = {"red": [], "stats": []}
+
+        def spy(self, dout):
+            r = orig_take(self, dout)
+            fired["red"].append(r is not None)
+            return r
+
+        def sspy(self, x):
+            r = orig_stake(self, x)
+            fired["stats"].append(r is not None)
+            return r
+        ops.TailLink.take, ops.StatsLink.take = spy, sspy
+        res = {}
+        for mode in (0, 1, 2):   # 2: chained, with a tap on the first unit's output
+            ops._cfg["chain_units"] = 1 if mode else 0
+            units = copy.deepcopy(u0)
+            x = x0.to(DEV).requires_grad_(True)
+            mid = units[0].f(enter(x))
+            out = leave(units[1].f(mid))
+            loss = out.square().mean()
+            if mode == 2:
+                loss = loss + 0.0 * leave(mid).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = ([out.detach().cpu(), x.grad.cpu()] + [p.grad.cpu() for u in units for p in u.parameters()] +
+                         [units[1].res_layer[0].running_mean.cpu(), units[1].res_layer[0].running_var.cpu()])
+        # backward order is unit 1 then unit 0.  unchained: no TailLink exists; chained: the second tail has no successor, the
+        # first takes; tapped: the delivery is refused
+        assert fired["red"] == [False, True, False, False], fired
+        # the output statistics are taken in both chained runs (+ the shortcut conv -> BatchNorm StatsLink of a widening unit)
+        assert fired["stats"].count(True) == 2 + 3 * (c0 != c1), fired
+        # bf16: a 1e-7 change of a statistic flips roundings downstream, so gradients that are sums with heavy cancellation
+        # (rms 1e-3 of the largest) are only held to an absolute bound on that scale
+        tol = 1e-3 if dtype == torch.float32 else 3e-2
+        rms = lambda t: float(t.double().norm()) / t.numel() ** 0.5
+        top = max(rms(b) for b in res[0][2:-2])
+        for k in (1, 2):
+            for a, b in zip(res[k], res[0]):
+                assert rel(a, b) < tol or (dtype == torch.bfloat16 and rms(a - b) < 1e-3 * top), (rel(a, b), rms(a - b), top)
+    finally:
+        ops.TailLink.take, ops.StatsLink.take = orig_take, orig_stake
+        ops._cfg["chain_units"] = 1
+        xrface.set_compute_dtype(torch.float32)
+
+
 def test_lr_synthesis_and_heatmaps_match_pil_and_reference_fixture():
     """SURVEY 8f-3 on the device: xr_lr_synth == the PIL calls of FHN_loader.py:65-66 bit for bit (uint8), its normalised output ==
     ToTensor + Normalize bit for bit (float32); xr_heatmap == the reference's generate_hm to float32 rounding."""

@@ -49,3 +49,31 @@ for H, C in SHAPES:
             t_ba = timeit(lambda: lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(sc), ptr(sh), None, None, 0, ptr(dy), ptr(coef), ptr(dx), None, pg, rows, C, 1, None, stream()))
             line += f" | stats {nbytes / t_st / 1e9:5.0f} fwd {2 * nbytes / t_fw / 1e9:5.0f} bred {2 * nbytes / t_br / 1e9:5.0f} bapp {3 * nbytes / t_ba / 1e9:5.0f} GB/s"
         print(line)
+
+# chained IR-SE units (ops.TailLink): separate passes vs the fused ones, in microseconds.  VARIANTS_CHAIN="8=1024,9=1024;..."
+print("\nchained units: tail apply + next statistics  |  opening-norm apply (with shortcut gradient) + tail reduce")
+for H, C in SHAPES:
+    M = N * H * H
+    HW = H * H
+    x = torch.randn(M, C, device=dev).bfloat16()
+    dy = torch.randn(M, C, device=dev).bfloat16()
+    y2 = torch.randn(M, C, device=dev).bfloat16()
+    sc_t = torch.randn(M, C, device=dev).bfloat16()
+    y = torch.empty_like(x)
+    dx = torch.empty_like(x)
+    cA, cB = torch.ones(N, C, device=dev), torch.zeros(N, C, device=dev)
+    sc1, sh1, coef1 = torch.ones(1, C, device=dev), torch.zeros(1, C, device=dev), torch.ones(3, 1, C, device=dev)
+    s2, s3 = torch.zeros(2, N, C, device=dev), torch.zeros(3, N, C, device=dev)
+    s32 = torch.zeros(2, 32, C, device=dev)
+    for v in os.environ.get("VARIANTS_CHAIN", "8=1024,9=1024;8=2048,9=2048;8=4096,9=4096").split(";"):
+        for kv in v.split(","):
+            k, val = kv.split("=")
+            lib.xr_tune(int(k), int(val))
+        t_fw = timeit(lambda: lib.xr_affine_act(dt(x), ptr(x), ptr(cA), ptr(cB), ptr(sc_t), None, 0, ptr(y), N, HW, C, 1, stream()))
+        t_st = timeit(lambda: lib.xr_group_stats(dt(y), ptr(y), ptr(s32), 32, M // 32, C, stream()))
+        t_fs = timeit(lambda: lib.xr_affine_act_stats(dt(x), ptr(x), ptr(cA), ptr(cB), ptr(sc_t), None, 0, ptr(y), ptr(s2), N, HW, C, 1, stream()))
+        t_ba = timeit(lambda: lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(sc1), ptr(sh1), None, None, 0, ptr(dy), ptr(coef1), ptr(dx), None, 1, M, C, 1, ptr(sc_t), stream()))
+        t_br = timeit(lambda: lib.xr_affine_act_bwd_reduce(dt(y2), ptr(y2), None, None, None, None, 0, ptr(dx), ptr(s3), N, HW, C, 1, stream()))
+        t_bf = timeit(lambda: lib.xr_affine_act_bwd_apply_red(dt(x), ptr(x), ptr(sc1), ptr(sh1), None, None, 0, ptr(dy), ptr(coef1), ptr(dx), None, N, HW, C, ptr(sc_t), ptr(y2), ptr(s2), stream()))
+        print(f"{H:3d}x{H:<3d} C={C:3d} [{v:16s}]  fwd {t_fw * 1e6:6.1f} + stats {t_st * 1e6:6.1f} = {(t_fw + t_st) * 1e6:6.1f} us -> fused {t_fs * 1e6:6.1f} us"
+              f"  |  apply {t_ba * 1e6:6.1f} + reduce {t_br * 1e6:6.1f} = {(t_ba + t_br) * 1e6:6.1f} us -> fused {t_bf * 1e6:6.1f} us")
