@@ -668,14 +668,20 @@ def test_chained_ir_se_units_share_statistics_and_backward_sums(c0, c1, stride, 
         assert fired["red"] == [False, True, False, False], fired
         # the output statistics are taken in both chained runs (+ the shortcut conv -> BatchNorm StatsLink of a widening unit)
         assert fired["stats"].count(True) == 2 + 3 * (c0 != c1), fired
-        # bf16: a 1e-7 change of a statistic flips roundings downstream, so gradients that are sums with heavy cancellation
-        # (rms 1e-3 of the largest) are only held to an absolute bound on that scale
-        tol = 1e-3 if dtype == torch.float32 else 3e-2
+        # The kernels themselves are checked bit for bit in test_fused_statistics_and_second_reduction_kernels; here the two paths
+        # sum the same reductions in a different order (1e-7 on a statistic), and that is enough to flip the sign of a
+        # pre-activation that sits within 1e-7 of the PReLU kink: ONE output-gradient element then changes its slope and the
+        # difference spreads to a weight-gradient row and everything upstream (tools/probe/chain_noise.py shows the same between
+        # two runs of the UNCHAINED path: L2 5e-4 / max-abs 1e-2).  Hence L2-relative bounds, not max-abs ones.
+        l2 = lambda a, b: float((a.double() - b.double()).norm() / max(float(b.double().norm()), 1e-30))
+        # Gradients that are analytically near zero (the shortcut BatchNorm's bias under this loss: sum of a normalised tensor) are
+        # pure rounding noise in bf16: those are held to an absolute bound on the scale of the largest parameter gradient.
+        tol, atol = (5e-3, 1e-5) if dtype == torch.float32 else (4e-2, 1e-3)
         rms = lambda t: float(t.double().norm()) / t.numel() ** 0.5
         top = max(rms(b) for b in res[0][2:-2])
         for k in (1, 2):
             for a, b in zip(res[k], res[0]):
-                assert rel(a, b) < tol or (dtype == torch.bfloat16 and rms(a - b) < 1e-3 * top), (rel(a, b), rms(a - b), top)
+                assert l2(a, b) < tol or rms(a - b) < atol * top, (k, tuple(a.shape), l2(a, b), rms(a - b), top)
     finally:
         ops.TailLink.take, ops.StatsLink.take = orig_take, orig_stake
         ops._cfg["chain_units"] = 1
@@ -719,3 +725,38 @@ def test_lr_synthesis_and_heatmaps_match_pil_and_reference_fixture():
     print(f"[heatmap] exact elements: {(hm == st['hm68']).mean():.4f} / {(hm2 == st['hm194']).mean():.4f}")
     g = gaussian_k(30.5, 40.25, 2.0, width=112, height=112).cpu().numpy()
     assert np.abs(g - R.gaussian_k(30.5, 40.25, 2.0, 112, 112).astype(np.float32)).max() <= 1.2e-7 and abs(g[40, 30] - np.exp(-(0.25 + 0.0625) / 8)) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,hw,c", [(32, 196, 256), (5, 49, 512), (6, 784, 128), (3, 400, 64), (2, 37, 24)])
+def test_fused_statistics_and_second_reduction_kernels(n, hw, c, dtype):
+    """xr_affine_act_stats == xr_affine_act + the sums of its stored output; xr_affine_act_bwd_apply_red == xr_affine_act_bwd_apply
+    (same dx bit for bit) + the per-image sums of (dx, dx * y2) -- against float64 sums of the stored values."""
+    from xrface._lib import lib, ptr, stream, dt
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    mk = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    x, res, dy, y2, add = (mk(n, hw, c).to(dtype) for _ in range(5))
+    cA, cB = mk(n, c), mk(n, c)
+    # forward: per-image coefficients + residual, as the IR-SE tail launches it
+    y_ref, y = torch.empty_like(x), torch.empty_like(x)
+    stats = torch.zeros(2, n, c, device=DEV)
+    lib.xr_affine_act(dt(x), ptr(x), ptr(cA), ptr(cB), ptr(res), None, 0, ptr(y_ref), n, hw, c, 1, stream())
+    lib.xr_affine_act_stats(dt(x), ptr(x), ptr(cA), ptr(cB), ptr(res), None, 0, ptr(y), ptr(stats), n, hw, c, 1, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref)
+    yd = y_ref.double()
+    for got, want, mag in ((stats[0], yd.sum(1), yd.abs().sum(1)), (stats[1], (yd * yd).sum(1), (yd * yd).sum(1))):
+        assert float(((got.double() - want).abs() / mag).max()) < 2e-6
+    # backward: one statistics group over the batch (coefficients per channel), shortcut gradient added, sums per image
+    sc, sh, coef = mk(1, c), mk(1, c), mk(3, 1, c)
+    dx_ref, dx = torch.empty_like(x), torch.empty_like(x)
+    red2 = torch.zeros(2, n, c, device=DEV)
+    lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(sc), ptr(sh), None, None, 0, ptr(dy), ptr(coef), ptr(dx_ref), None, 1, n * hw, c, 1,
+                                ptr(add), stream())
+    lib.xr_affine_act_bwd_apply_red(dt(x), ptr(x), ptr(sc), ptr(sh), None, None, 0, ptr(dy), ptr(coef), ptr(dx), None, n, hw, c,
+                                    ptr(add), ptr(y2), ptr(red2), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    dd, wd = dx_ref.double(), y2.double()
+    for got, want, mag in ((red2[0], dd.sum(1), dd.abs().sum(1)), (red2[1], (dd * wd).sum(1), (dd * wd).abs().sum(1))):
+        assert float(((got.double() - want).abs() / mag).max()) < 2e-6
