@@ -152,7 +152,7 @@ class Backbone(Module):
     # -- fused NHWC path ---------------------------------------------------------------------------
     def f_input(self, buf):
         il = self.input_layer
-        return xnn.conv_bn(il[0], il[1], buf, act="prelu", alpha=il[2].weight)
+        return xnn.conv_bn(il[0], il[1], buf, act="prelu", alpha=il[2].weight, offer_stats=True)
 
     def f_output(self, buf):
         ol = self.output_layer

@@ -135,13 +135,13 @@ class _BNMixin:
             self.__dict__["_xr_eval_coef"] = hit
         return hit[1]
 
-    def f(self, buf, res=None, act=None, alpha=None, slink=None):
+    def f(self, buf, res=None, act=None, alpha=None, slink=None, offer_stats=False):
         training = self.training or not self.track_running_stats
         self._count()
         mom = self._momentum()
         coef = None if training or torch.is_grad_enabled() and _any_requires_grad(self) else self._eval_coef()
         return ops.norm_act(buf, self.weight, self.bias, self.running_mean, self.running_var, res, alpha, "bn", act, training,
-                            mom, self.eps, slink if training else None, coef)
+                            mom, self.eps, slink if training else None, coef, offer_stats)
 
 
 
@@ -264,11 +264,12 @@ def res_trunk(seq, buf, times):
     return buf
 
 
-def conv_bn(conv, bn, buf, res=None, act=None, alpha=None, pass_through=False):
+def conv_bn(conv, bn, buf, res=None, act=None, alpha=None, pass_through=False, offer_stats=False):
     """conv -> BatchNorm(+residual, +activation) with the batch statistics taken in the convolution's epilogue.
-    pass_through: also return buf' (aliasing buf) for an identity branch whose gradient the conv's dgrad epilogue sums in."""
+    pass_through: also return buf' (aliasing buf) for an identity branch whose gradient the conv's dgrad epilogue sums in.
+    offer_stats: the result opens a residual unit (ops.norm_act)."""
     link = ops.StatsLink() if (bn.training or not bn.track_running_stats) else None
     if pass_through:
         y, bufp = conv.f_pass(buf, link)
         return bn.f(y, res=res, act=act, alpha=alpha, slink=link), bufp
-    return bn.f(conv.f(buf, link), res=res, act=act, alpha=alpha, slink=link)
+    return bn.f(conv.f(buf, link), res=res, act=act, alpha=alpha, slink=link, offer_stats=offer_stats)

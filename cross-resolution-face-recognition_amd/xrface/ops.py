@@ -900,7 +900,7 @@ class _NormAct(Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, passthrough=False, link=None,
-                slink=None, eval_coef=None, tail=None):
+                slink=None, eval_coef=None, tail=None, offer=None):
         x = _c(x)
         N, H, W, C = x.shape
         ctx.passthrough = passthrough
@@ -958,7 +958,15 @@ class _NormAct(Function):
                 lib.xr_bn_eval_coeffs(ptr(gm), ptr(bt), ptr(rmean), ptr(rvar), ptr(scale), ptr(shift), C, eps, stream())
         y = torch.empty_like(x)
         a = _ACT[act]
-        lib.xr_affine_act(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), G, rows, C, 1, stream())
+        if offer is not None and mode == "bn" and N > 1:
+            # the output opens a residual unit whose BatchNorm wants its statistics: one group per image, shared coefficients
+            osum = zeros_f32((2, N, C), dev)
+            lib.xr_affine_act_stats(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), ptr(osum), N, H * W, C, 0,
+                                    stream())
+            offer.slink = StatsLink()
+            offer.slink.deliver(y, osum)
+        else:
+            lib.xr_affine_act(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), G, rows, C, 1, stream())
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, gm, al, rmean, rvar)
         ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
         ctx.prefs = (gamma, beta, alpha)
@@ -1050,7 +1058,7 @@ class _NormAct(Function):
         elif dx is not None or dres is not None:
             lib.xr_affine_act_bwd_apply(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
                                         ptr(dres), G, rows, C, 1, ptr(dpass), stream())
-        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None, None, None, None
 
 
 class BnLink:
@@ -1117,8 +1125,15 @@ def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", ac
 
 
 def norm_act(x, gamma=None, beta=None, rmean=None, rvar=None, res=None, alpha=None, mode="none", act=None, training=True,
-             momentum=0.1, eps=EPS, slink=None, eval_coef=None):
-    return _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, False, None, slink, eval_coef)
+             momentum=0.1, eps=EPS, slink=None, eval_coef=None, offer_stats=False):
+    """offer_stats: the output feeds a residual unit that opens with a training-mode BatchNorm (the IR input layer): its
+    statistics are taken in this pass and travel with the output (TailLink without a backward half)."""
+    offer = TailLink() if (offer_stats and mode == "bn" and training and _cfg["chain_units"]) else None
+    y = _NormAct.apply(x, gamma, beta, rmean, rvar, res, alpha, mode, act, training, momentum, eps, False, None, slink, eval_coef,
+                       None, offer)
+    if offer is not None and offer.slink is not None:
+        y._xr_tail = offer
+    return y
 
 
 def bn_eval_coeffs(gamma, beta, rmean, rvar, eps):

@@ -760,3 +760,43 @@ def test_fused_statistics_and_second_reduction_kernels(n, hw, c, dtype):
     dd, wd = dx_ref.double(), y2.double()
     for got, want, mag in ((red2[0], dd.sum(1), dd.abs().sum(1)), (red2[1], (dd * wd).sum(1), (dd * wd).abs().sum(1))):
         assert float(((got.double() - want).abs() / mag).max()) < 2e-6
+
+
+def test_input_layer_offers_statistics_to_the_first_unit():
+    """Backbone.f_input (conv -> BatchNorm -> PReLU, model_irse.py:141-143) takes the statistics of its output in the same pass;
+    the first unit's opening BatchNorm must pick them up and produce the running statistics / outputs of the separate pass."""
+    import copy
+    import xrface
+    from xrface import ops
+    from xrface.model.model_irse import Backbone, bottleneck_IR_SE
+    from xrface.ops import enter, leave
+    orig = ops.StatsLink.take
+    try:
+        torch.manual_seed(3)
+        net0 = Backbone([112, 112], 50, 'ir_se')
+        il0, u0 = net0.input_layer.to(DEV).train(), net0.body[0].to(DEV).train()
+        x = rnd("inl", 4, 3, 24, 24).to(DEV)
+        res, hits = {}, []
+
+        def spy(self, t):
+            r = orig(self, t)
+            hits.append(r is not None)
+            return r
+        ops.StatsLink.take = spy
+        for mode in (0, 1):
+            ops._cfg["chain_units"] = mode
+            net = copy.deepcopy(net0)
+            net.input_layer, net.body = copy.deepcopy(il0), torch.nn.Sequential(copy.deepcopy(u0))
+            y = net.f_input(enter(x))
+            assert (getattr(y, "_xr_tail", None) is not None) == bool(mode)
+            out = leave(net.body[0].f(y))
+            torch.cuda.synchronize()
+            bn = net.body[0].res_layer[0]
+            res[mode] = [out.detach().cpu(), bn.running_mean.cpu(), bn.running_var.cpu()]
+        # takes per run: the input layer's conv -> BatchNorm link, then (chained only) the offered statistics
+        assert hits == [True, True, True], hits
+        for a, b in zip(res[1], res[0]):
+            assert rel(a, b) < 1e-5
+    finally:
+        ops.StatsLink.take = orig
+        ops._cfg["chain_units"] = 1
