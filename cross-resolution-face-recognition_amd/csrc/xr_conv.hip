@@ -589,7 +589,7 @@ constexpr size_t igemm_smem() {
 }
 
 }  // namespace
-XrTune g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
+XrTune g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 1, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [13] 8-wave ring weight gradient (xr_wgrad8.hip): 0 off, 1 auto (K >= 256), 2 whenever eligible; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
 namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
@@ -661,17 +661,7 @@ int launch_igemm_f(IgemmP& p, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
-struct WgradP {
-  const void* in;
-  const void* dy;
-  float* dwp;
-  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c, tiles_all;
-  FastDiv fd_howo, fd_wo;
-  int a64, b64, c64;            // 64 pixels = a64 images + b64 rows + c64 columns (per-step cursor advance)
-  int d64, dwrap_w, dwrap_h;    // byte deltas of the gather offset: per 64-pixel advance, per column wrap, per row wrap
-  int prio;                     // raise wave priority around the MFMA clusters (tuning knob 5)
-  unsigned in_bytes, dy_bytes;  // buffer-descriptor extents (FAST path)
-};
+// (WgradP: xr_conv_p.h)
 
 // transposing fragment fetch from a [pixel][col] LDS image (pitch bytes): 8 pixels x 1 column per lane
 __device__ __forceinline__ bf16x8_t tr_frag(const unsigned char* img, int pitch, int pix0, int col0, int lane) {
@@ -1609,6 +1599,7 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
   WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0, 0, g_tune[5], 0, 0};
   hipStream_t st = (hipStream_t)stream;
   const bool tall = K > 64;
+  if (dtype == XR_BF16 && xr_wgrad8_eligible(p, transposed)) return xr_wgrad8_launch(p, split, st);   // wide layers: xr_wgrad8.hip
   if (dtype == XR_BF16) {
     if (tall) return transposed ? launch_wgrad<0, 128, 128, true>(p, split, st) : launch_wgrad<0, 128, 128, false>(p, split, st);
     return transposed ? launch_wgrad<0, 64, 256, true>(p, split, st) : launch_wgrad<0, 64, 256, false>(p, split, st);

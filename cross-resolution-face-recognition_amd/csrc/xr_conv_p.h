@@ -74,6 +74,23 @@ __device__ __forceinline__ void decode_pixel(int m, int M, const FastDiv& fd_how
 
 
 
+// weight-gradient launch parameters (xr_conv.hip: 4-wave sliced kernel; xr_wgrad8.hip: 8-wave ring kernel)
+struct WgradP {
+  const void* in;
+  const void* dy;
+  float* dwp;
+  int N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, M, steps_total, steps_per_split, tiles_c, tiles_all;
+  FastDiv fd_howo, fd_wo;
+  int a64, b64, c64;            // 64 pixels = a64 images + b64 rows + c64 columns (per-step cursor advance)
+  int d64, dwrap_w, dwrap_h;    // byte deltas of the gather offset: per 64-pixel advance, per column wrap, per row wrap
+  int prio;                     // raise wave priority around the MFMA clusters (tuning knob 5)
+  unsigned in_bytes, dy_bytes;  // buffer-descriptor extents (FAST path)
+};
+
+// 8-wave 128x256-tile weight gradient with a three-stage LDS ring (xr_wgrad8.hip): bf16, forward gather
+bool xr_wgrad8_eligible(const WgradP& p, int transposed);
+int xr_wgrad8_launch(WgradP& p, int split, hipStream_t st);
+
 // 8-wave 256x256 tile path (xr_conv8.hip).  xr_igemm8_eligible() decides from the problem alone; the launcher returns
 // XR_OK or a negative error code like every other launcher.
 bool xr_igemm8_eligible(const IgemmP& p, int dtype, int transposed);

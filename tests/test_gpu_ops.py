@@ -800,3 +800,53 @@ def test_input_layer_offers_statistics_to_the_first_unit():
     finally:
         ops.StatsLink.take = orig
         ops._cfg["chain_units"] = 1
+
+
+WGRAD8_CASES = [
+    # N, C, H, W, K, R, stride, pad, split
+    (8, 256, 14, 14, 256, 3, 1, 1, 14),
+    (4, 256, 14, 14, 512, 3, 1, 1, 7),
+    (8, 512, 7, 7, 512, 3, 1, 1, 3),
+    (4, 256, 28, 28, 256, 3, 2, 1, 5),
+    (3, 128, 9, 9, 192, 3, 1, 1, 2),     # second row tile half empty, ragged last column tile
+    (2, 72, 11, 13, 136, 3, 1, 1, 3),    # C not a multiple of 64: padded reduction columns; K not a multiple of 128
+    (4, 256, 14, 14, 512, 1, 1, 0, 4),   # 1x1
+    (1, 256, 6, 6, 256, 3, 1, 1, 1),     # a single ragged stage
+]
+
+
+@pytest.mark.parametrize("case", WGRAD8_CASES)
+def test_wgrad_8wave_ring_kernel(case):
+    """xr_wgrad8.hip (8 waves, 128 x 256 tile, three-stage LDS ring, counted vmcnt) forced on (xr_tune knob 13 = 2) against the
+    4-wave sliced kernel on the same operands through the C ABI: both cut the pixels into the same slices and add the same
+    16-pixel MFMA steps in the same order, so every slab must agree bit for bit; then against the fp32 reference; twice (race
+    screen: the ring's only ordering is one s_barrier per stage)."""
+    from xrface import ops
+    from xrface._lib import lib, ptr, stream, dt
+    N, C, H, W, K, R, stride, pad, split = case
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    x = rnd(f"w8x{case}", N, C, H, W).bfloat16()
+    gy = rnd(f"w8g{case}", N, K, Ho, Wo).bfloat16()
+    Cp, Kp = ops.r8(C), ops.r8(K)
+    kg = ops.kg_of(R * R, Cp)
+    xb = torch.zeros(N, H, W, Cp, dtype=torch.bfloat16); xb[..., :C] = x.permute(0, 2, 3, 1)
+    gb = torch.zeros(N, Ho, Wo, Kp, dtype=torch.bfloat16); gb[..., :K] = gy.permute(0, 2, 3, 1)
+    xb, gb = xb.to(DEV), gb.to(DEV)
+    out = {}
+    try:
+        for knob in (0, 2, 2):
+            lib.xr_tune(13, knob)
+            slabs = torch.full((split, K, kg), float("nan"), device=DEV)
+            n = lib.xr_conv_wgrad(dt(xb), ptr(xb), ptr(gb), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, R, stride, pad, 0, Kp, kg, split,
+                                  stream())
+            torch.cuda.synchronize()
+            out.setdefault(knob, []).append((n, slabs[:n].cpu()))
+    finally:
+        lib.xr_tune(13, 1)
+    (n0, s0), (n8, s8), (_, s8b) = out[0][0], out[2][0], out[2][1]
+    assert n0 == n8 and not torch.isnan(s8).any()
+    assert torch.equal(s8, s8b)
+    assert torch.equal(s8, s0)
+    dw = s8.sum(0)[:, :R * R * Cp].reshape(K, R * R, Cp)[:, :, :C].permute(0, 2, 1).reshape(K, C, R, R)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (K, C, R, R), gy.float(), stride=stride, padding=pad)
+    assert rel(dw, ref) < 2e-5

@@ -46,7 +46,7 @@ for spec in os.environ.get("VARIANTS", "base:;wprio:5=1").split(";"):
     name, kv = spec.split(":")
     variants.append((name, [tuple(p.split("=")) for p in kv.split(",") if p]))
 cfg0 = dict(ops._cfg)
-defaults = {0: 3, 2: 0, 3: 0, 4: 1, 5: 1, 6: 18, 7: 1, 11: 0, 12: 1}
+defaults = {0: 3, 2: 0, 3: 0, 4: 1, 5: 1, 6: 18, 7: 1, 11: 0, 12: 1, 13: 1}
 
 
 def apply(kvs):
