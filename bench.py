@@ -75,6 +75,12 @@ def _kernel_of(tag, batch):
     if kind == "wgrad":
         if C == 64 and K == 64 and R == 3 and stride == 1 and W % 8 == 0 and W <= 112:
             return "wgrad64_kernel<%d chunks/row> (direct, xr_wgrad64.hip)" % (-(-W // 16) if W > 64 else (4 if W > 32 else 2))
+        Wo = W // stride
+        if (R == 3 and C % 64 == 0 and K % 64 == 0 and H % stride == 0 and W % stride == 0 and 14 <= Wo <= (112 if stride == 1 else 64)
+                and ((stride == 1 and C <= 128) or (stride == 2 and C == 64))):   # ops._wgrad_rows_ok, mode 2
+            return "wgrad_rows_kernel (row-walking direct, xr_wgrad_rows.hip)"
+        if K >= 256 and C >= 256 and K % 128 == 0:   # xr_wgrad8_eligible
+            return "wgrad8_kernel (8 waves, 128x256 tile, 3-stage LDS ring, xr_wgrad8.hip)"
         return "wgrad_kernel<0, %s, ...>" % ("128, 128" if K > 64 else "64, 256")
     Ho, Wo = _out_hw(H, W, R, stride)
     gk, gc, m = (K, C, batch * Ho * Wo) if kind == "fwd" else (C, K, batch * H * W)    # GEMM columns, reduction channels, rows

@@ -24,10 +24,12 @@ namespace {
 constexpr int NTW = 512;
 constexpr int BP = 64;                       // pixels per stage
 constexpr int BR = 128, BC = 256;            // tile: k rows x (tap, c) columns
-constexpr int PY = BR * 2, PX = BC * 2;      // LDS row pitches (bytes): unpadded, 16-B chunks XOR-swizzled
-constexpr int CRY = BR / 8, CRX = BC / 8;    // 16-B chunks per image row
-constexpr int NY = BP * CRY / NTW, NX = BP * CRX / NTW;   // DMA pieces per thread and stage: 2 + 4
-constexpr int STAGE = BP * (PY + PX);        // 48 KiB
+constexpr int PY = BR * 2;                   // dY image: [64 pixels][128 k], unpadded rows, 16-B chunks XOR-swizzled
+constexpr int PX = 128, NSUB = BC / 64;      // X image: four sub-images [64 pixels][64 columns] (one per wave column)
+constexpr int SUB = BP * PX;                 // 8 KiB
+constexpr int CRY = BR / 8, CRX = PX / 16;   // 16-B chunks per image row
+constexpr int NY = BP * CRY / NTW, NX = NSUB;             // DMA pieces per thread and stage: 2 + 4
+constexpr int STAGE = BP * PY + NSUB * SUB;  // 48 KiB
 constexpr int NRING = 3;
 #define XRW_OOR 0x80000000u
 
@@ -49,7 +51,8 @@ __device__ __forceinline__ bf16x8_t frag(unsigned base) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 // per-lane byte offset of the fragment that starts at column col0 (a multiple of 32) of an image with pitch R: row =
-// 8*h + q (+ pix0, a multiple of 16: same swizzle term), 16-B chunk XOR-swizzled by (row & 3) << 2 as in xr_conv.hip
+// 8*h + q (+ pix0, a multiple of 16: same swizzle term), 16-B chunk XOR-swizzled as in xr_conv.hip (pitch >= 256: by
+// (row & 3) << 2; pitch 128: by ((row >> 1) & 1) << 2)
 template <int R>
 __device__ __forceinline__ unsigned frag_off(int col0, int lane) {
   const int g = lane >> 4, i = lane & 15;
@@ -57,7 +60,8 @@ __device__ __forceinline__ unsigned frag_off(int col0, int lane) {
   const int cgrp = g & 1, h = g >> 1;
   const int row = 8 * h + q;
   const int cb = (col0 + 16 * cgrp + 4 * pp) * 2;
-  return (unsigned)(row * R + ((((cb >> 4) ^ ((row & 3) << 2)) << 4) | (cb & 15)));
+  const int swz = R >= 256 ? (row & 3) << 2 : ((row >> 1) & 1) << 2;   // wg_swz<R> of xr_conv.hip
+  return (unsigned)(row * R + ((((cb >> 4) ^ swz) << 4) | (cb & 15)));
 }
 
 template <int N>
@@ -81,15 +85,16 @@ __global__ __launch_bounds__(NTW, 1) void wgrad8_kernel(WgradP p) {
   const int tile_c = tile % p.tiles_c, tile_r = tile / p.tiles_c;
   const int r0 = tile_r * BR, c0 = tile_c * BC;
 
-  // ---- DMA slots: the thread's LDS slot is fixed, it fetches the source chunk that the swizzle maps into it
+  // ---- DMA slots: the thread's LDS slot is fixed, it fetches the source chunk that the swizzle maps into it.
+  // X: wave w stages pixel rows 8w..8w+7 of all four sub-images, so the four pieces of a lane are the SAME pixel and tap
+  // (the tile's 256 columns are one tap: C % 256 == 0), 64 channels apart: ONE gather cursor per lane.
   const int xrow0 = t / CRX, yrow0 = t / CRY;
-  const int xch = (t % CRX) ^ ((xrow0 & 3) << 2);
+  const int xch = (t % CRX) ^ (((xrow0 >> 1) & 1) << 2);
   const int ych = (t % CRY) ^ ((yrow0 & 3) << 2);
-  const int j0 = c0 + xch * 8;
-  const int tap = j0 / p.C;
-  const int cch = j0 - tap * p.C;
+  const int tap = c0 / p.C;
+  const int cch = c0 - tap * p.C + xch * 8;
   const int tr_ = tap / p.S, ts_ = tap - tr_ * p.S;
-  const bool col_ok = (tap < p.R * p.S) && (j0 < p.Kg);
+  const bool col_ok = tap < p.R * p.S;
   const int adv_w = p.c64 * p.stride, adv_h = p.b64 * p.stride, span_w = p.Wo * p.stride, span_h = p.Ho * p.stride;
   const int wlim = span_w + ts_ - p.pad, hlim = span_h + tr_ - p.pad;
   const bool ycol_ok = (r0 + ych * 8) < p.ldy;
@@ -104,19 +109,18 @@ __global__ __launch_bounds__(NTW, 1) void wgrad8_kernel(WgradP p) {
   if (s_end > p.steps_total) s_end = p.steps_total;
   if (s_begin >= s_end) return;   // (whole workgroup: the slice is uniform)
 
-  // per-slot gather cursor: byte offset of the tap's input pixel, its input row / column for the bounds test; a 64-pixel
-  // advance is three adds plus two wrap corrections with launch-uniform deltas
-  int xl[NX], xhv[NX], xwv[NX];
-#pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    const int m = s_begin * BP + xrow0 + (NTW / CRX) * i;
+  // gather cursor of the lane's pixel: byte offset of the tap's input pixel, its input row / column for the bounds test; a
+  // 64-pixel advance is three adds plus two wrap corrections with launch-uniform deltas
+  int xl, xhv, xwv;
+  {
+    const int m = s_begin * BP + xrow0;
     const int n = fdiv(p.fd_howo, m);
     const int rem = m - n * (int)p.fd_howo.d;
     const int ho = fdiv(p.fd_wo, rem);
     const int wo = rem - ho * (int)p.fd_wo.d;
-    xhv[i] = ho * p.stride - p.pad + tr_;
-    xwv[i] = wo * p.stride - p.pad + ts_;
-    xl[i] = (((n * p.H + xhv[i]) * p.W + xwv[i]) * p.C + cch) * 2;
+    xhv = ho * p.stride - p.pad + tr_;
+    xwv = wo * p.stride - p.pad + ts_;
+    xl = (((n * p.H + xhv) * p.W + xwv) * p.C + cch) * 2;
   }
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -138,30 +142,36 @@ __global__ __launch_bounds__(NTW, 1) void wgrad8_kernel(WgradP p) {
     (void)step; (void)buf;
 #endif
   };
-  auto dma_x = [&](int step, int buf, int i0) {   // X pieces i0, i0 + 1
+  unsigned x_voff = XRW_OOR;
+  auto dma_x_addr = [&](int step) {   // validity + offset of the lane's pixel for stage `step`, then advance the cursor
+    const bool ok = step < s_end && col_ok && step * BP + xrow0 < p.M && (unsigned)xhv < (unsigned)p.H && (unsigned)xwv < (unsigned)p.W;
+    x_voff = ok ? (unsigned)xl : XRW_OOR;
+    int w2 = xwv + adv_w, h2 = xhv + adv_h, l2 = xl + p.d64;
+    if (w2 >= wlim) { w2 -= span_w; h2 += p.stride; l2 += p.dwrap_w; }
+    if (h2 >= hlim) { h2 -= span_h; l2 += p.dwrap_h; }
+    xwv = w2; xhv = h2; xl = l2;
+  };
+  auto dma_x = [&](int buf, int i0) {   // X pieces i0, i0 + 1 (sub-images i0, i0 + 1: 64 channels = 128 bytes apart)
 #if defined(__HIP_DEVICE_COMPILE__)
-    unsigned char* sX = smem + buf * STAGE + BP * PY;
-    const int mbase = step * BP;
-    const bool live = step < s_end;
-#pragma unroll
-    for (int i = i0; i < i0 + 2; ++i) {
-      const bool ok = live && col_ok && mbase + xrow0 + (NTW / CRX) * i < p.M && (unsigned)xhv[i] < (unsigned)p.H &&
-                      (unsigned)xwv[i] < (unsigned)p.W;
-      const unsigned voff = ok ? (unsigned)xl[i] : XRW_OOR;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + (wv * (64 / CRX) + (NTW / CRX) * i) * PX), 16, voff, 0, 0, 0);
-      int w2 = xwv[i] + adv_w, h2 = xhv[i] + adv_h, l2 = xl[i] + p.d64;
-      if (w2 >= wlim) { w2 -= span_w; h2 += p.stride; l2 += p.dwrap_w; }
-      if (h2 >= hlim) { h2 -= span_h; l2 += p.dwrap_h; }
-      xwv[i] = w2; xhv[i] = h2; xl[i] = l2;
+    unsigned char* sX = smem + buf * STAGE + BP * PY + wv * 1024;
+    // the 64-channel step goes into the scalar offset: an instruction offset would also move the LDS destination, and the
+    // range check (which supplies the zero padding) looks at the vector offset only
+    if (i0 == 0) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + 0 * SUB), 16, x_voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + 1 * SUB), 16, x_voff, 128, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + 2 * SUB), 16, x_voff, 256, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_t)(sX + 3 * SUB), 16, x_voff, 384, 0, 0);
     }
 #else
-    (void)step; (void)buf; (void)i0;
+    (void)buf; (void)i0;
 #endif
   };
   auto dma_stage = [&](int step, int buf) {
     dma_y(step, buf);
-    dma_x(step, buf, 0);
-    dma_x(step, buf, 2);
+    dma_x_addr(step);
+    dma_x(buf, 0);
+    dma_x(buf, 2);
   };
   static_assert(NX == 4 && NY == 2, "three parts of two pieces");
 
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(NTW, 1) void wgrad8_kernel(WgradP p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     ya[i] = lds0 + frag_off<PY>(wr0 + i * 32, lane);
-    xa[i] = lds0 + (unsigned)(BP * PY) + frag_off<PX>(wc0 + i * 32, lane);
+    xa[i] = lds0 + (unsigned)(BP * PY + (wave & 3) * SUB) + frag_off<PX>(i * 32, lane);
   }
 
   f32x16_t acc[2][2];
@@ -217,11 +227,12 @@ __global__ __launch_bounds__(NTW, 1) void wgrad8_kernel(WgradP p) {
     __builtin_amdgcn_sched_barrier(0);      // address arithmetic runs while the four MFMAs just issued execute
     XRW_RD(2, 0)
     XRW_MMA(1, 8)
-    dma_x(step + 2, nb, 0);
+    dma_x_addr(step + 2);
+    dma_x(nb, 0);
     __builtin_amdgcn_sched_barrier(0);
     XRW_RD(3, 1)
     XRW_MMA(0, 8)
-    dma_x(step + 2, nb, 2);
+    dma_x(nb, 2);
     __builtin_amdgcn_sched_barrier(0);
     XRW_MMA(1, 0)
     if (++buf == NRING) buf = 0;
@@ -252,9 +263,9 @@ bool xr_wgrad8_eligible(const WgradP& p, int transposed) {
   if (knob == 0 || transposed) return false;
   const long long in_bytes = (long long)p.N * p.H * p.W * p.C * 2, dy_bytes = (long long)p.M * p.ldy * 2;
   if (in_bytes >= (1ll << 31) || dy_bytes >= (1ll << 31) || g_tune[2] != 0) return false;
-  if (p.C % 8 != 0 || p.Kg % 64 != 0) return false;
+  if (p.C % 256 != 0 || p.Kg % 256 != 0) return false;   // a 256-column tile is one tap (one gather cursor per lane)
   if (knob == 2) return p.K > 64;              // forced (tests / tuning)
-  return p.K >= 256 && p.C >= 256 && p.K % 128 == 0;   // measured (tools/wgrad8_bench.py): 7-15 % faster there, slower on the 128-channel layers
+  return p.K >= 256 && p.K % 128 == 0;   // measured (tools/wgrad8_bench.py): 7-15 % faster there, slower on the 128-channel layers
 }
 
 int xr_wgrad8_launch(WgradP& p, int split, hipStream_t st) {

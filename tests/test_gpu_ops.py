@@ -808,10 +808,12 @@ WGRAD8_CASES = [
     (4, 256, 14, 14, 512, 3, 1, 1, 7),
     (8, 512, 7, 7, 512, 3, 1, 1, 3),
     (4, 256, 28, 28, 256, 3, 2, 1, 5),
-    (3, 128, 9, 9, 192, 3, 1, 1, 2),     # second row tile half empty, ragged last column tile
-    (2, 72, 11, 13, 136, 3, 1, 1, 3),    # C not a multiple of 64: padded reduction columns; K not a multiple of 128
+    (3, 128, 9, 9, 192, 3, 1, 1, 2),     # C % 256 != 0: not eligible even when forced -- must fall back to the 4-wave kernel
+    (2, 72, 11, 13, 136, 3, 1, 1, 3),    # (same)
     (4, 256, 14, 14, 512, 1, 1, 0, 4),   # 1x1
     (1, 256, 6, 6, 256, 3, 1, 1, 1),     # a single ragged stage
+    (2, 512, 10, 10, 384, 3, 1, 1, 2),   # three row tiles, two taps' worth of column tiles per tap
+    (3, 256, 14, 14, 264, 3, 1, 1, 3),   # ragged last row tile (264 = 2 x 128 + 8)
 ]
 
 

@@ -25,7 +25,7 @@ for f in sorted(glob.glob(root + "/[ab]*/p_counter_collection.csv")):
     disp = collections.OrderedDict()
     for r in rows:
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("igemm", "wgrad_kernel", "wgrad64", "dconv64")):
+        if not any(s in k for s in ("igemm", "wgrad_kernel", "wgrad8_kernel", "wgrad64", "dconv64")):
             continue
         disp.setdefault(int(r["Dispatch_Id"]), {"kernel": k})[r["Counter_Name"]] = float(r["Counter_Value"])
     seq = [disp[d] for d in sorted(disp)]
