@@ -217,6 +217,8 @@ def _timed(fn, warm, reps):
         out = fn()
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) * 1e3)
+    if os.environ.get("XR_BENCH_TRACE"):
+        print("  timed: " + " ".join(f"{t:.2f}" for t in ts), file=sys.stderr, flush=True)
     ts.sort()
     return ts[len(ts) // 2], out
 
@@ -252,7 +254,7 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
                 parallel.FusedRMSprop(flats[2], lr=1e-4, alpha=0.99, weight_decay=1e-5)]
         hr, _ = synth_batch(c4_batch, dev, 11)
         lr = synth_lr(hr)
-        ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts), 2, 5)
+        ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts), 3, 7)
         (sl, al), _ = res
         tf = C4_STEP_GFLOP * c4_batch / ms            # GFLOP per ms = TFLOP/s
         out.append({"workload": "C4 (BASELINE configs[3], per-GPU shape): root FHN (trainable) -> IR-SE-50 student + assistant vs frozen "
@@ -274,7 +276,7 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
         lr = synth_lr(hr)
         hm = torch.rand(c3_batch, 28, 28, device=dev)
         par = torch.randint(0, 11, (c3_batch, 1, 28, 28), device=dev)
-        ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts), 2, 5)
+        ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts), 3, 7)
         tf = 3.0 * FHN_FWD_GFLOP * c3_batch / ms
         out.append({"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
                                 "parsing losses, per-network gradients, RMSprop x4",

@@ -40,6 +40,28 @@ if os.environ.get("WORKLOAD") == "kd":  # residual KD step (BASELINE config 4 sh
         steps.kd_step(teacher, student, assistant, xk, so, ao)
 
 
+if os.environ.get("WORKLOAD") == "c4":  # the composed north-star step (BASELINE configs[3]): FHN -> IR-SE-50 student + assistant vs teacher
+    from xrface import steps
+    from xrface.model import FSRnet, model_irse
+    n = int(os.environ.get("N", 256))
+    fhn = {"coarse": FSRnet.Course_SR_Network().to(dev), "prior": FSRnet.Prior_Estimation_Network().to(dev),
+           "encoder": FSRnet.Fine_SR_Encoder().to(dev), "decoder": FSRnet.Fine_SR_Decoder().to(dev)}
+    student, assistant = model_irse.IR_SE_50([112, 112]).to(dev), model_irse.IR_SE_50([112, 112]).to(dev)
+    teacher = model_irse.IR_SE_50([112, 112]).to(dev).eval()
+    for p_ in teacher.parameters():
+        p_.requires_grad_(False)
+    fp = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]
+    flats = [parallel.FlatParams(fp), parallel.FlatParams(student.parameters_in_execution_order()),
+             parallel.FlatParams(assistant.parameters_in_execution_order())]
+    opts4 = [parallel.FusedRMSprop(f, lr=1e-5, weight_decay=1e-5) for f in flats]
+    hr4 = bench.synth_batch(n, dev, 11)[0]
+    lr4 = bench.synth_lr(hr4)
+    del model, flat, opt
+
+    def step():
+        steps.c4_step(fhn, student, assistant, teacher, lr4, hr4, optimizers=opts4)
+
+
 # VARIANTS="name:knob=val,knob=val;..." ; special key: wb = ops wgrad_blocks
 variants = []
 for spec in os.environ.get("VARIANTS", "base:;wprio:5=1").split(";"):
