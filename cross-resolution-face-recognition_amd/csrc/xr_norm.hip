@@ -571,6 +571,10 @@ __global__ __launch_bounds__(NT) void se_excite_bwd_kernel(const float* __restri
   }
 }
 
+// squeeze widths the all-at-once dot products below handle (a power of two between 4 and 64: NT / Cr lanes per output fold
+// inside one wave); anything else takes the one-output-per-wave loops
+__device__ __forceinline__ bool se_fast(int Cr) { return Cr >= 4 && Cr <= 64 && (Cr & (Cr - 1)) == 0; }
+
 // ---- fused BatchNorm -> SE -> (+shortcut) tail of bottleneck_IR_SE (model_irse.py:76-91) ---------------------------
 // With r = a*y + b (BatchNorm as a per-channel affine) the SE squeeze is pooled_r = a*mean_hw(y) + b, so r is never
 // materialised: out = y*(a*s) + (b*s) + shortcut.  Forward kernel: one block per image.
@@ -590,19 +594,35 @@ __global__ __launch_bounds__(NT) void bnse_fwd_kernel(const float* __restrict__ 
     pooled[c] = ps / hw;
   }
   __syncthreads();
-  for (int j = wave; j < Cr; j += NT / 64) {
+  if (se_fast(Cr)) {
+    // all Cr dot products at once: NT / Cr adjacent lanes per output walk c (coalesced rows of w1), shuffle-xor fold -- one
+    // round trip to memory instead of Cr / 4 dependent ones per wave (these kernels sit on the critical path of every unit)
+    const int G = NT / Cr, j = t / G, cl = t - j * G;
     float v = 0.f;
-    for (int c = lane; c < C; c += 64) v += w1[(size_t)j * C + c] * pooled[c];
-    v = wave_sum(v);
-    if (lane == 0) {
+#pragma unroll 4
+    for (int c = cl; c < C; c += G) v += w1[(size_t)j * C + c] * pooled[c];
+    for (int o = G >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (cl == 0) {
       v = v > 0.f ? v : 0.f;
       hid[j] = v;
       hidden[(size_t)n * Cr + j] = v;
+    }
+  } else {
+    for (int j = wave; j < Cr; j += NT / 64) {
+      float v = 0.f;
+      for (int c = lane; c < C; c += 64) v += w1[(size_t)j * C + c] * pooled[c];
+      v = wave_sum(v);
+      if (lane == 0) {
+        v = v > 0.f ? v : 0.f;
+        hid[j] = v;
+        hidden[(size_t)n * Cr + j] = v;
+      }
     }
   }
   __syncthreads();
   for (int c = t; c < C; c += NT) {
     float v = 0.f;
+#pragma unroll 8
     for (int j = 0; j < Cr; ++j) v += w2[(size_t)c * Cr + j] * hid[j];
     const float sv = 1.f / (1.f + __expf(-v));
     s[(size_t)n * C + c] = sv;
@@ -619,7 +639,7 @@ __global__ __launch_bounds__(NT) void bnse_bwd_excite_kernel(const float* __rest
                                                              const float* __restrict__ hidden, const float* __restrict__ s,
                                                              float* __restrict__ dpre2, float* __restrict__ dhid,
                                                              float* __restrict__ dp, int C, int Cr, float hw) {
-  extern __shared__ float lds[];  // d2[C] + dh[Cr]
+  extern __shared__ float lds[];  // d2[C] + dh[Cr] + part[4 * Cr]
   float* d2 = lds;
   float* dh = lds + C;
   const int n = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -632,19 +652,41 @@ __global__ __launch_bounds__(NT) void bnse_bwd_excite_kernel(const float* __rest
     dpre2[i] = v;
   }
   __syncthreads();
-  for (int j = wave; j < Cr; j += NT / 64) {
+  if (se_fast(Cr)) {
+    // w2 is [C][Cr]: adjacent lanes walk j (coalesced rows), NT / Cr lane groups walk c; fold the groups of a wave by
+    // shuffle-xor (same j sits Cr lanes apart), the four waves through LDS
+    float* part = dh + Cr;   // [NT / 64][Cr]
+    const int G = NT / Cr, j = t % Cr, cl = t / Cr;
     float v = 0.f;
-    for (int c = lane; c < C; c += 64) v += w2[(size_t)c * Cr + j] * d2[c];
-    v = wave_sum(v);
-    if (lane == 0) {
-      v = hidden[(size_t)n * Cr + j] > 0.f ? v : 0.f;
-      dh[j] = v;
-      dhid[(size_t)n * Cr + j] = v;
+#pragma unroll 4
+    for (int c = cl; c < C; c += G) v += w2[(size_t)c * Cr + j] * d2[c];
+    for (int o = Cr; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    if (lane < Cr) part[wave * Cr + lane] = v;
+    __syncthreads();
+    if (t < Cr) {
+      float u = 0.f;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) u += part[w * Cr + t];
+      u = hidden[(size_t)n * Cr + t] > 0.f ? u : 0.f;
+      dh[t] = u;
+      dhid[(size_t)n * Cr + t] = u;
+    }
+  } else {
+    for (int j = wave; j < Cr; j += NT / 64) {
+      float v = 0.f;
+      for (int c = lane; c < C; c += 64) v += w2[(size_t)c * Cr + j] * d2[c];
+      v = wave_sum(v);
+      if (lane == 0) {
+        v = hidden[(size_t)n * Cr + j] > 0.f ? v : 0.f;
+        dh[j] = v;
+        dhid[(size_t)n * Cr + j] = v;
+      }
     }
   }
   __syncthreads();
   for (int c = t; c < C; c += NT) {
     float v = 0.f;
+#pragma unroll 8
     for (int j = 0; j < Cr; ++j) v += w1[(size_t)j * C + c] * dh[j];
     dp[(size_t)n * C + c] = v / hw;
   }
@@ -665,12 +707,14 @@ __global__ __launch_bounds__(NT) void bnse_bwd_coeffs_kernel(const float* __rest
   const int c = blockIdx.x * 8 + cl;
   const bool live = c < C;
   float t1 = 0.f, t2 = 0.f;
-  if (live)
-    for (int n = lane; n < N; n += 32) {
+  if (live) {
+#pragma unroll 4
+    for (int n = lane; n < N; n += 32) {   // (unrolled: the five loads of four images in flight together)
       const size_t i = (size_t)n * C + c;
       t1 += s[i] * S1[i] + hw * dp[i];
       t2 += s[i] * S2[i] + dp[i] * sum_y[i];
     }
+  }
   part[0][lane][cl] = t1;
   part[1][lane][cl] = t2;
   __syncthreads();
@@ -921,7 +965,7 @@ extern "C" int xr_bnse_bwd(const float* S1, const float* S2, const float* sum_y,
   XR_CHECK_ARG(S1 && S2 && sum_y && a && b && w1 && w2 && hidden && s && mean && invstd && dpre2 && dhid && dp && coef &&
                    N > 0 && C > 0 && Cr > 0 && C <= 4096 && HW > 0,
                "xr_bnse_bwd: bad arguments");
-  hipLaunchKernelGGL(bnse_bwd_excite_kernel, dim3(N), dim3(NT), (C + Cr) * sizeof(float), (hipStream_t)stream, S1, S2, a, b, w1,
+  hipLaunchKernelGGL(bnse_bwd_excite_kernel, dim3(N), dim3(NT), (C + 5 * Cr) * sizeof(float), (hipStream_t)stream, S1, S2, a, b, w1,
                      w2, hidden, s, dpre2, dhid, dp, C, Cr, (float)HW);
   XR_CHECK_LAUNCH("xr_bnse_bwd(excite)");
   hipLaunchKernelGGL(bnse_bwd_coeffs_kernel, dim3(cdiv(C, 8)), dim3(NT), 0, (hipStream_t)stream, S1, S2, s, dp, sum_y,

@@ -77,3 +77,16 @@ for H, C in SHAPES:
         t_bf = timeit(lambda: lib.xr_affine_act_bwd_apply_red(dt(x), ptr(x), ptr(sc1), ptr(sh1), None, None, 0, ptr(dy), ptr(coef1), ptr(dx), None, N, HW, C, ptr(sc_t), ptr(y2), ptr(s2), stream()))
         print(f"{H:3d}x{H:<3d} C={C:3d} [{v:16s}]  fwd {t_fw * 1e6:6.1f} + stats {t_st * 1e6:6.1f} = {(t_fw + t_st) * 1e6:6.1f} us -> fused {t_fs * 1e6:6.1f} us"
               f"  |  apply {t_ba * 1e6:6.1f} + reduce {t_br * 1e6:6.1f} = {(t_ba + t_br) * 1e6:6.1f} us -> fused {t_bf * 1e6:6.1f} us")
+
+# the per-unit glue of the IR-SE tail (latency chains on the critical path of every unit): xr_bnse_fwd, xr_bnse_bwd
+print("\nIR-SE tail glue (microseconds per call)")
+for H, C in SHAPES:
+    Cr, HW = C // 16, H * H
+    f = lambda *s: torch.randn(*s, device=dev)
+    sum_y, a, b, w1, w2 = f(N, C), f(C), f(C), f(Cr, C) * 0.1, f(C, Cr) * 0.1
+    pooled, hidden, s_, cA, cB = f(N, C), f(N, Cr), f(N, C), f(N, C), f(N, C)
+    S1, S2, gamma, mean, invstd = f(N, C), f(N, C), f(C), f(C), f(C).abs() + 0.5
+    dpre2, dhid, dp, coef, dg, db = f(N, C), f(N, Cr), f(N, C), f(3, N, C), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    t_f = timeit(lambda: lib.xr_bnse_fwd(ptr(sum_y), ptr(a), ptr(b), ptr(w1), ptr(w2), ptr(pooled), ptr(hidden), ptr(s_), ptr(cA), ptr(cB), N, C, Cr, HW, stream()), reps=50)
+    t_b = timeit(lambda: lib.xr_bnse_bwd(ptr(S1), ptr(S2), ptr(sum_y), ptr(a), ptr(b), ptr(w1), ptr(w2), ptr(hidden), ptr(s_), ptr(gamma), ptr(mean), ptr(invstd), ptr(dpre2), ptr(dhid), ptr(dp), ptr(coef), ptr(dg), ptr(db), N, C, Cr, HW, 1, stream()), reps=50)
+    print(f"{H:3d}x{H:<3d} C={C:3d} Cr={Cr:2d}:  fwd {t_f * 1e6:6.1f} us   bwd (excite + coeffs) {t_b * 1e6:6.1f} us")
