@@ -193,11 +193,13 @@ __global__ __launch_bounds__(256) void norm_finalize_fold_kernel(const float* __
   const int cl = threadIdx.x & 7, fl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   float s0 = 0.f, s1 = 0.f;
-  if (c < C)
-    for (int f = fl; f < fold; f += 32) {
+  if (c < C) {
+#pragma unroll 4
+    for (int f = fl; f < fold; f += 32) {   // (unrolled: per-image partials, fold = N, keep eight loads in flight)
       s0 += sums[(size_t)f * C + c];
       s1 += sums[((size_t)fold + f) * C + c];
     }
+  }
   part[0][fl][cl] = s0;
   part[1][fl][cl] = s1;
   __syncthreads();
