@@ -710,11 +710,22 @@ __global__ __launch_bounds__(NT) void bnse_bwd_coeffs_kernel(const float* __rest
   const bool live = c < C;
   float t1 = 0.f, t2 = 0.f;
   if (live) {
-#pragma unroll 4
-    for (int n = lane; n < N; n += 32) {   // (unrolled: the five loads of four images in flight together)
-      const size_t i = (size_t)n * C + c;
-      t1 += s[i] * S1[i] + hw * dp[i];
-      t2 += s[i] * S2[i] + dp[i] * sum_y[i];
+    // eight images per pass with all forty loads issued before the first use: this launch is a latency chain on the critical
+    // path of every unit (a rolled loop made it eight dependent round trips)
+    for (int n0 = lane; n0 < N; n0 += 32 * 8) {
+      float vs[8], v1[8], v2[8], vd[8], vy[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int n = n0 + 32 * k;
+        const size_t i = (size_t)(n < N ? n : n0) * C + c;
+        vs[k] = n < N ? s[i] : 0.f;
+        v1[k] = S1[i]; v2[k] = S2[i]; vd[k] = n < N ? dp[i] : 0.f; vy[k] = sum_y[i];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        t1 += vs[k] * v1[k] + hw * vd[k];
+        t2 += vs[k] * v2[k] + vd[k] * vy[k];
+      }
     }
   }
   part[0][lane][cl] = t1;
