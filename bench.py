@@ -81,7 +81,8 @@ def _kernel_of(tag, batch):
             return "wgrad_rows_kernel (row-walking direct, xr_wgrad_rows.hip)"
         if K >= 256 and C >= 256 and K % 128 == 0:   # xr_wgrad8_eligible
             return "wgrad8_kernel (8 waves, 128x256 tile, 3-stage LDS ring, xr_wgrad8.hip)"
-        return "wgrad_kernel<0, %s, ...>" % ("128, 128" if K > 64 else "64, 256")
+        kg = -(-(C * R * R) // 64) * 64
+        return "wgrad_kernel<0, %s, ...>" % ("128, 128" if (K > 64 or kg <= 128) else "64, 256")
     Ho, Wo = _out_hw(H, W, R, stride)
     gk, gc, m = (K, C, batch * Ho * Wo) if kind == "fwd" else (C, K, batch * H * W)    # GEMM columns, reduction channels, rows
     ok = gk % 8 == 0 and gc % 64 == 0 and R * R <= 32 and gc * R * R >= 512 and (kind == "fwd" or stride == 1)

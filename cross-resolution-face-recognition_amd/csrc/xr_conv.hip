@@ -1610,7 +1610,9 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
   XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 31), "xr_conv_wgrad: too many pixels");
   WgradP p{in, dy, dwp, N, H, W, C, Ho, Wo, K, R, S, stride, pad, ldy, Kg, N * Ho * Wo, 0, 0, 0, 0, {}, {}, 0, 0, 0, 0, 0, 0, g_tune[5], 0, 0};
   hipStream_t st = (hipStream_t)stream;
-  const bool tall = K > 64;
+  // 128 x 128 tile for K > 64 and for short reduction rows (Kg <= 128: the 3 -> 64 stems, 1x1 convolutions of <= 128 channels):
+  // the 64 x 256 tile would stage 256 columns of which at most 128 exist (stem weight gradient 253 -> 213 us)
+  const bool tall = K > 64 || Kg <= 128;
   if (dtype == XR_BF16 && xr_wgrad8_eligible(p, transposed)) return xr_wgrad8_launch(p, split, st);   // wide layers: xr_wgrad8.hip
   if (dtype == XR_BF16) {
     if (tall) return transposed ? launch_wgrad<0, 128, 128, true>(p, split, st) : launch_wgrad<0, 128, 128, false>(p, split, st);

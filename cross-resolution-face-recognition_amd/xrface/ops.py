@@ -432,9 +432,11 @@ def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
 
 
 def _wgrad_split(M, K, kg):
-    tiles = ((K + 127) // 128) * ((kg + 127) // 128) if K > 64 else ((kg + 255) // 256)
+    tiles = ((K + 127) // 128) * ((kg + 127) // 128) if (K > 64 or kg <= 128) else ((kg + 255) // 256)
     steps = (M + 63) // 64
-    return max(1, min(steps, _cfg["wgrad_blocks"] // max(tiles, 1), 256))
+    # a one-tile problem (the 3 -> 64 stems: 32 KB slabs) takes two workgroups per CU: 253 -> 144 us at 112 x 112, batch 256
+    cap = 512 if (tiles == 1 and K * kg <= 16384) else 256
+    return max(1, min(steps, _cfg["wgrad_blocks"] // max(tiles, 1), cap))
 
 
 # ------------------------------------------------------------------------------------------------- layout
