@@ -121,11 +121,12 @@ __global__ __launch_bounds__(NT, 3) void wgrad_rows_kernel(WGRP p) {
   const int ri_base = S * r0 - 1;            // flattened input row of local input row 0
   const int in_rows = p.N * p.H;
 
-  v4u_t st[NSTG];
-  bool wr[NSTG];
+  // two register sets: the loads of step t + 2 are issued while step t is multiplied and step t + 1's set waits to be written
+  v4u_t st0[NSTG], st1[NSTG];
+  bool wr0[NSTG], wr1[NSTG];
   // li0: local index of the first of the S * RS input rows to stage (may be negative in the prologue: those rows are skipped);
   // lo0: local index of the first of the RS dY rows, or a negative number for none
-  auto stage_load = [&](int li0, int lo0) {
+  auto stage_load = [&](v4u_t (&st)[NSTG], bool (&wr)[NSTG], int li0, int lo0) {
     const long long xbase = (long long)(ri_base + li0) * xrow_bytes, ybase = (long long)(r0 + lo0) * yrow_bytes;
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) {
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NT, 3) void wgrad_rows_kernel(WGRP p) {
     }
   };
   // ypar: which half of the dY ring the RS rows go to
-  auto stage_write = [&](int li0, int ypar) {
+  auto stage_write = [&](v4u_t (&st)[NSTG], bool (&wr)[NSTG], int li0, int ypar) {
 #pragma unroll
     for (int i = 0; i < NSTG; ++i) {
       if (kind[i] == 2) continue;
@@ -183,18 +184,19 @@ __global__ __launch_bounds__(NT, 3) void wgrad_rows_kernel(WGRP p) {
   // prologue: local input rows 0 .. C0 - 1 in NP stages of S * RS rows ending at C0 - 1; dY rows 0 .. RS - 1 with the last one
 #pragma unroll
   for (int k = NP - 1; k >= 0; --k) {
-    stage_load(C0 - (k + 1) * SRS, k == 0 ? 0 : -1);
-    stage_write(C0 - (k + 1) * SRS, 0);
+    stage_load(st0, wr0, C0 - (k + 1) * SRS, k == 0 ? 0 : -1);
+    stage_write(st0, wr0, C0 - (k + 1) * SRS, 0);
   }
   __syncthreads();
 
   int h = r0 % p.Ho;
   int xb = 0;                                   // ring slot of local input row S * it * RS
-  int it = 0;
-  for (int r = r0; r < r1; r += RS, ++it) {
-    const bool more = r + RS < r1;
+  // one step: issue the loads of step it + 2 into (stL, wrL), multiply step it, write step it + 1's rows -- loaded one step ago
+  // into (stW, wrW) -- to LDS.  With one step of lookahead (12-42 MFMAs per wave) every step waited a full memory round trip.
+  auto step = [&](int r, int it, v4u_t (&stL)[NSTG], bool (&wrL)[NSTG], v4u_t (&stW)[NSTG], bool (&wrW)[NSTG]) {
+    const bool more = r + RS < r1, more2 = r + 2 * RS < r1;
     const int li_next = S * it * RS + C0;       // first input row the next step needs beyond this step's
-    stage_load(li_next, more ? (it + 1) * RS : -1);
+    if (more2) stage_load(stL, wrL, li_next + SRS, (it + 2) * RS);
 #pragma unroll
     for (int j = 0; j < RS; ++j) {
       int ho = h + j;
@@ -217,12 +219,18 @@ __global__ __launch_bounds__(NT, 3) void wgrad_rows_kernel(WGRP p) {
         }
       }
     }
-    if (more) stage_write(li_next, (it + 1) & 1);
+    if (more) stage_write(stW, wrW, li_next, (it + 1) & 1);
     __syncthreads();
     h += RS;
     if (h >= p.Ho) h %= p.Ho;
     xb += SRS;
     if (xb >= NXR) xb -= NXR;
+  };
+  if (r0 + RS < r1) stage_load(st0, wr0, C0, RS);     // step 1's rows
+  int it = 0;
+  for (int r = r0; r < r1; r += 2 * RS, it += 2) {
+    step(r, it, st1, wr1, st0, wr0);
+    if (r + RS < r1) step(r + RS, it + 1, st0, wr0, st1, wr1);
   }
 
   const int Kg = 9 * p.C;
