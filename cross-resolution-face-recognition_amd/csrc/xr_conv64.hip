@@ -73,6 +73,7 @@ struct DC64P {
   const bf16_t* ep_add;   // laid out like out: residual gradient (EP == 2, 4) or the norm input c1 (EP == 3)
   const bf16_t* ep_c;     // EP == 4: the previous block's c2 (norm input of its tail) and x (its residual input)
   const bf16_t* ep_x;
+  bf16_t* out2;           // EP == 5: second output prelu(out, n_alpha), laid out like out
   const float* n_scale;   // [N][64] per-image affine applied to the input on load (NORM)
   const float* n_shift;
   const float* n_alpha;   // [64] PReLU slope applied after the affine, or null (no activation)
@@ -95,6 +96,9 @@ struct TileGeo {          // wave-uniform description of one tile
 // 4 out = prelu'(tail) * (conv + ep_add) with the reductions of the previous block's tail
 template <bool TR, bool NORM, int EP>
 __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
+  constexpr bool ADD = EP >= 2 && EP <= 4;   // a second input laid out like the output is loaded in the epilogue
+  constexpr bool RED = EP == 3 || EP == 4;   // backward reductions over the output
+
   constexpr int NPB = 4;   // pixel blocks (32 pixels = 2 image rows x 16 columns) per wave
   constexpr int NSLOT = 36 * NPB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -130,14 +134,15 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   }
   const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in), 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.io_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_out2 = __builtin_amdgcn_make_buffer_rsrc(EP == 5 ? p.out2 : p.out, 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_add =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP >= 2 ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ADD ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 4 ? p.ep_c : p.in), 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 4 ? p.ep_x : p.in), 0, p.io_bytes, 0x00020000);
   float sc[8], sh[8], al[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = 1.f, sh[e] = 0.f, al[e] = 1.f;
-  if ((NORM || EP >= 3) && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
+  if ((NORM || RED || EP == 5) && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
   int n_staged = -1;
 
   auto geo_of = [&](int tl) {
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     return ((om >> i) & 1u) ? (unsigned)(base + orel0 + i * orstep) : XR64_OOR;
   };
   auto add_load = [&](int base, unsigned om, int i) {
-    if constexpr (EP >= 2) addv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, out_voff(base, om, i), 0, 0);
+    if constexpr (ADD) addv[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, out_voff(base, om, i), 0, 0);
   };
   auto tail_load = [&](int base, unsigned om, int i, int which) {
     if constexpr (EP == 4) {
@@ -272,6 +277,17 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       v = v4u_t{o[0], o[1], o[2], o[3]};
     }
     __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, voff, 0, 0);
+    if constexpr (EP == 5) {   // second output: PReLU of the value just stored (what the next convolution consumes)
+      unsigned o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = __uint_as_float(v[q] << 16), b = __uint_as_float(v[q] & 0xFFFF0000u);
+        a = a > 0.f ? a : a * al[2 * q];
+        b = b > 0.f ? b : b * al[2 * q + 1];
+        o[q] = pack2bf(a, b);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(v4u_t{o[0], o[1], o[2], o[3]}, rs_out2, voff, 0, 0);
+    }
     if constexpr (EP == 1) {
       const bool ok = (om >> i) & 1u;
 #pragma unroll
@@ -312,14 +328,14 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
       float c3 = 0.f;
-      if constexpr (EP >= 3) {
+      if constexpr (RED) {
         c3 = b3[e];
         c3 += __shfl_xor(c3, 8, 64); c3 += __shfl_xor(c3, 16, 64); c3 += __shfl_xor(c3, 32, 64);
       }
       if (lane < 8 && n_stats >= 0) {
         atomicAdd(p.stats + (size_t)n_stats * 64 + cc * 8 + e, a);
         atomicAdd(p.stats + ((size_t)p.N + n_stats) * 64 + cc * 8 + e, b);
-        if constexpr (EP >= 3) atomicAdd(p.stats + ((size_t)2 * p.N + n_stats) * 64 + cc * 8 + e, c3);
+        if constexpr (RED) atomicAdd(p.stats + ((size_t)2 * p.N + n_stats) * 64 + cc * 8 + e, c3);
       }
       bs[e] = 0.f;
       bss[e] = 0.f;
@@ -327,10 +343,10 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     }
   };
   auto stats_image = [&](int n) {   // wave-uniform: called before the first stream-out item of a tile
-    if ((EP == 1 || EP >= 3) && n != n_stats) {
+    if ((EP == 1 || RED) && n != n_stats) {
       if (n_stats >= 0) flush_stats();
       n_stats = n;
-      if constexpr (EP >= 3) {      // coefficients of z = c1 * scale + shift for the image being streamed out
+      if constexpr (RED) {      // coefficients of z = c1 * scale + shift for the image being streamed out
         ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
         ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
       }
@@ -431,8 +447,8 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
           if constexpr (k == rd + 3) out_store(pbase, om, i);
         });
       } else {
-      constexpr int RD = EP >= 2 ? 69 : 36, ST = EP >= 2 ? 6 : 8;
-      if constexpr (EP >= 2 && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
+      constexpr int RD = ADD ? 69 : 36, ST = ADD ? 6 : 8;
+      if constexpr (ADD && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
       if constexpr (k >= RD && k < RD + ST * NOUT && (k - RD) % ST == 0) out_read((k - RD) / ST);
       if constexpr (k >= RD + 3 && k < RD + 3 + ST * NOUT && (k - RD - 3) % ST == 0) out_store(pbase, om, (k - RD - 3) / ST);
       }
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       out_store(prv.base, om, i);
     }
   }
-  if (EP == 1 || EP >= 3) flush_stats();
+  if (EP == 1 || RED) flush_stats();
 }
 
 template <bool TR, bool NORM, int EP>
@@ -534,6 +550,10 @@ int launch_dconv64_ep(DC64P& p, int grid, hipStream_t st) {
     } else {
       return XR_E_INVALID;
     }
+  }
+  if (p.out2 != nullptr) {
+    if constexpr (!TR && !NORM) return launch_dconv64<false, false, 5>(p, grid, st);
+    else return XR_E_INVALID;
   }
   if (p.stats != nullptr) return launch_dconv64<TR, NORM, 1>(p, grid, st);
   if (p.ep_add != nullptr) return launch_dconv64<TR, NORM, 2>(p, grid, st);
@@ -582,6 +602,18 @@ extern "C" int xr_conv64_direct(const void* in, const void* wpack, const float* 
   p.N = N; p.H = H; p.W = W;
   p.io_bytes = (unsigned)io_bytes;
   return dconv64_run(p, transposed, in_scale != nullptr, (hipStream_t)stream);
+}
+
+extern "C" int xr_conv64_direct_prelu(const void* in, const void* wpack, void* out, void* out2, const float* alpha, int N, int H,
+                                      int W, void* stream) {
+  XR_CHECK_ARG(in && wpack && out && out2 && alpha && N > 0 && H > 0 && W > 0, "xr_conv64_direct_prelu: null pointer / non-positive dimension");
+  const long long io_bytes = (long long)N * H * W * 64 * 2;
+  XR_CHECK_ARG(io_bytes < (1ll << 31), "xr_conv64_direct_prelu: tensor larger than 2 GiB (use xr_conv_igemm)");
+  DC64P p{};
+  p.in = (const bf16_t*)in; p.w = (const bf16_t*)wpack; p.out = (bf16_t*)out; p.out2 = (bf16_t*)out2; p.n_alpha = alpha;
+  p.N = N; p.H = H; p.W = W;
+  p.io_bytes = (unsigned)io_bytes;
+  return dconv64_run(p, 0, false, (hipStream_t)stream);
 }
 
 extern "C" int xr_conv64_direct_bwdred(const void* in, const void* wpack, void* out, int N, int H, int W, int transposed,

@@ -20,7 +20,7 @@ import os as _os
 _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_WGRAD_BLOCKS", "512")), "dalpha_spread": 32, "pack_plan": 1, "wgrad_stream": int(_os.environ.get("XR_WGRAD_STREAM", "1")), "fuse_prelu": 1, "fold_finalize": 1, "fuse_bn_reduce": 1, "fuse_conv_stats": 1, "direct64": int(_os.environ.get("XR_DIRECT64", "1")),
         "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2")),
         "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
-        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")),
+        "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")), "direct64_prelu": 1,
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0"))}
 
 
@@ -579,8 +579,13 @@ class _Conv2d(Function):
             ssp = StatsLink.SPREAD
             sred = zeros_f32((3, ssp, Kp), x.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
-                          kg, Kp, None, 0, None, ptr(al), None, ssp, ptr(p2), ptr(sred), None, stream())
+        if p2 is not None and bf is None and sred is None and _cfg["direct64_prelu"] and direct64_ok(x, w, stride, pad):
+            # conv1 of the 64-channel IR units: the direct kernel with the PReLU second output (its backward keeps the
+            # implicit-GEMM / bwdred paths below: ctx.direct64 stays False)
+            lib.xr_conv64_direct_prelu(ptr(x), ptr(pk), ptr(y), ptr(p2), ptr(al), N, H, W, stream())
+        else:
+            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
+                              kg, Kp, None, 0, None, ptr(al), None, ssp, ptr(p2), ptr(sred), None, stream())
         if sred is not None:
             stats_link.deliver(y, sred)
         if pe is not None:
@@ -790,11 +795,14 @@ class _PreluConv2d(Function):
         pk, kg = _packed(w, "fwd", y1.dtype, K, 1, R * S, C, Cp, C * R * S, 0, 1, R * S)
         Kp = r8(K)
         y2 = torch.empty((N, Ho, Wo, Kp), dtype=y1.dtype, device=y1.device)
-        pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
-        lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
-                          None, None, None, 1, None, None, None, stream())
-        if pe is not None:
-            pe.record()
+        if _cfg["direct64_prelu"] and direct64_ok(p1, w, stride, pad):
+            _conv64(p1, pk, y2, tag=("fwd", Cp, K, H, W, R, stride))      # 64 -> 64 stride 1: the direct kernel
+        else:
+            pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
+            lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
+                              None, None, None, 1, None, None, None, stream())
+            if pe is not None:
+                pe.record()
         ctx.save_for_backward(y1, p1, w, al)
         ctx.geom = (stride, pad)
         ctx.alpha_ref = alpha

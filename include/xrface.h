@@ -122,6 +122,11 @@ int xr_conv64_direct(const void* in, const void* wpack, const float* bias, void*
                      const float* in_scale, const float* in_shift, const float* in_alpha, float* out_stats, const void* ep_add,
                      void* stream);
 
+/* The forward convolution (no bias) with a SECOND output out2 = prelu(out, alpha[k]) taken from the rounded value just stored:
+ * conv -> PReLU -> conv of the IR units (model_irse.py:57-61) -- the activation pass disappears, as with xr_conv_igemm's ep2_out. */
+int xr_conv64_direct_prelu(const void* in, const void* wpack, void* out, void* out2, const float* alpha, int N, int H, int W,
+                           void* stream);
+
 /* The same convolution (no bias, no on-load transform) whose OUTPUT is the gradient dy of y = prelu(c * red_scale[n] + red_shift[n],
  * red_alpha) -- conv2's input gradient in the FSRNet residual block (model/FSRnet.py:81-85): while the output streams out, the
  * epilogue loads the matching chunk of c = red_src (laid out like out) and accumulates, per image n and channel,

@@ -400,3 +400,30 @@ def test_chained_residual_trunk_matches_block_by_block(shape, flat):
         ct, cb = cos(gt[k], gr[k]), cos(gb[k], gr[k])
         assert ct > 0.99 and ct > cb - 5e-3, (k, ct, cb)
         assert cos(gt[k], gb[k]) > 0.995, (k, cos(gt[k], gb[k]))
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 20, 24), (2, 112, 112), (5, 7, 7)])
+def test_direct_conv_with_prelu_second_output(n, h, w):
+    """xr_conv64_direct_prelu (conv1 of the 64-channel IR units, model_irse.py:57-59): y against the fp32 reference convolution of
+    the bf16 operands, and the second output bit for bit = PReLU of the STORED y (what xr_conv_igemm's ep2_out delivers)."""
+    import xrface
+    from xrface import ops
+    from xrface._lib import lib, ptr, stream
+    g = torch.Generator().manual_seed(n * 100 + h)
+    x = torch.randn(n, h, w, 64, generator=g).bfloat16().to(DEV)
+    wt = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(DEV)
+    alpha = (torch.rand(64, generator=g) * 0.5).to(DEV)
+    xrface.set_compute_dtype(torch.bfloat16)
+    try:
+        pk, kg = ops._packed(wt, "fwd", torch.bfloat16, 64, 1, 9, 64, 64, 64 * 9, 0, 1, 9)
+        y, p2 = torch.empty_like(x), torch.empty_like(x)
+        lib.xr_conv64_direct_prelu(ptr(x), ptr(pk), ptr(y), ptr(p2), ptr(alpha), n, h, w, stream())
+        torch.cuda.synchronize()
+    finally:
+        xrface.set_compute_dtype(torch.float32)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2).cpu(), wt.bfloat16().float().cpu(), padding=1).permute(0, 2, 3, 1)
+    err = float((y.float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-2, err
+    yf = y.float()
+    want = torch.where(yf > 0, yf, yf * alpha.view(1, 1, 1, 64)).bfloat16()
+    assert torch.equal(p2, want)
