@@ -83,6 +83,10 @@ def _kernel_of(tag, batch):
             return "wgrad8_kernel (8 waves, 128x256 tile, 3-stage LDS ring, xr_wgrad8.hip)"
         kg = -(-(C * R * R) // 64) * 64
         return "wgrad_kernel<0, %s, ...>" % ("128, 128" if (K > 64 or kg <= 128) else "64, 256")
+    if C == 64 and K == 64 and R == 3 and stride == 1:   # ops.direct64_ok: the 64-channel stride-1 layers of the IR units
+        if kind == "fwd":
+            return "dconv64_kernel (direct, xr_conv64.hip; conv1 with the PReLU second output)"
+        return "dconv64_kernel (conv1: BatchNorm sums in the epilogue) + igemm_kernel<dgrad, 4 waves> (conv2: PReLU-backward epilogue)"
     Ho, Wo = _out_hw(H, W, R, stride)
     gk, gc, m = (K, C, batch * Ho * Wo) if kind == "fwd" else (C, K, batch * H * W)    # GEMM columns, reduction channels, rows
     ok = gk % 8 == 0 and gc % 64 == 0 and R * R <= 32 and gc * R * R >= 512 and (kind == "fwd" or stride == 1)

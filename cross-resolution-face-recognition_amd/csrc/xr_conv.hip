@@ -1212,31 +1212,23 @@ __global__ __launch_bounds__(256) void unpack_fwdform_kernel(const float* __rest
   const int s_end = (s_beg + spg < nslices) ? s_beg + spg : nslices;
   const bool atomic = gridDim.z > 1;
   const int nb = (B - b0) < 64 ? (B - b0) : 64;
-  // 16-byte loads: 16 lanes cover the 64 b of one tap row (Bp and b0 are multiples of 8, slabs are 16-byte aligned), 16 tap
-  // rows per pass, four slices in flight per thread -- 64 B per lane instead of 16 (the 4-byte form ran at 1.7 TB/s cold)
-  const int l16 = t & 15;
-  for (int tp = t >> 4; tp < taps; tp += 16) {
-    const float4* sp = reinterpret_cast<const float4*>(packed + (int64_t)a * Kg + (int64_t)tp * Bp + b0) + l16;
-    const int64_t st4 = slice_stride >> 2;
-    float4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+  // (a 16-byte-load form of this loop -- 16 lanes per tap row, 16 tap rows per pass -- was 12 % faster in isolation, 20.4 -> 17.9 us
+  // cold, and 70-80 % SLOWER inside the FHN steps, where it runs beside the persistent direct weight-gradient workgroups: fewer
+  // active lanes per block hide less latency under contention.  Kept: one 4-byte element per lane, four slices in flight.)
+  for (int e = t; e < 64 * taps; e += 256) {
+    const int tp = e >> 6, bl = e & 63;
+    if (bl >= nb) continue;
+    const float* sp = packed + (int64_t)a * Kg + (int64_t)tp * Bp + b0 + bl;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
     int sl = s_beg;
     for (; sl + 3 < s_end; sl += 4) {
-      const float4 q0 = sp[sl * st4], q1 = sp[(sl + 1) * st4], q2 = sp[(sl + 2) * st4], q3 = sp[(sl + 3) * st4];
-      v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
-      v1.x += q1.x; v1.y += q1.y; v1.z += q1.z; v1.w += q1.w;
-      v2.x += q2.x; v2.y += q2.y; v2.z += q2.z; v2.w += q2.w;
-      v3.x += q3.x; v3.y += q3.y; v3.z += q3.z; v3.w += q3.w;
+      v0 += sp[sl * slice_stride];
+      v1 += sp[(sl + 1) * slice_stride];
+      v2 += sp[(sl + 2) * slice_stride];
+      v3 += sp[(sl + 3) * slice_stride];
     }
-    for (; sl < s_end; ++sl) {
-      const float4 q0 = sp[sl * st4];
-      v0.x += q0.x; v0.y += q0.y; v0.z += q0.z; v0.w += q0.w;
-    }
-    const int bl = 4 * l16;
-    const float r[4] = {(v0.x + v1.x) + (v2.x + v3.x), (v0.y + v1.y) + (v2.y + v3.y), (v0.z + v1.z) + (v2.z + v3.z),
-                        (v0.w + v1.w) + (v2.w + v3.w)};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (bl + k < nb) tile[(bl + k) * taps + tp] = r[k];
+    for (; sl < s_end; ++sl) v0 += sp[sl * slice_stride];
+    tile[bl * taps + tp] = (v0 + v1) + (v2 + v3);
   }
   __syncthreads();
   float* dp = dst + ((int64_t)a * B + b0) * taps;
@@ -1489,8 +1481,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   XR_CHECK_ARG(packed && dst && nslices >= 1, "xr_unpack_wgrad: null pointer / nslices < 1");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Kg >= taps * Bp, "xr_unpack_wgrad: bad dims");
   const int64_t total = (int64_t)A1 * A2 * taps * B;
-  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 2 && taps <= 64 && A1 <= 65535 && B >= 32 &&
-      Bp % 4 == 0 && Kg % 4 == 0 && ((uintptr_t)packed & 15) == 0) {
+  if (A2 == 1 && st_ == 1 && sb == taps && sa1 == (int64_t)B * taps && taps >= 2 && taps <= 64 && A1 <= 65535 && B >= 32) {
     // Conv2d [K][C][R][S] / Linear-as-7x7-conv parameters: the taps are the fastest axis of the parameter and the slowest of
     // the pack -- LDS-tiled so both sides stay coalesced (a strided read-modify-write of the parameter layout ran at 1.3 TB/s)
     const int tiles = cdiv(B, 64) * A1;
