@@ -164,6 +164,23 @@ def pmc_traffic(kernel, site):
         return None
 
 
+def step_roofline(tag, ms, batch):
+    """HBM view of a whole secondary step (C3 / C4 are HBM-bound): bytes per step from this round's
+    committed PMC pass over a profiled step (profiles/r03_step_traffic.json: sum over all kernels of 2 x FETCH_SIZE + WRITE_SIZE,
+    MI355X_MICROARCH.md HBM section), taken at the batch the step is timed at, against 8 TB/s; None until that file exists."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_step_traffic.json")) as f:
+            db = json.load(f)[tag]
+        if db["batch"] != batch:
+            return None
+        gb = db["hbm_bytes_per_step"] / 1e9
+        return {"bound": "hbm", "achieved": round(gb / (ms * 1e-3), 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(gb / (ms * 1e-3) / PEAK_HBM_GBS, 4), "traffic": db["hbm_bytes_per_step"],
+                "algorithmic_bytes_per_step": db.get("algorithmic_bytes_per_step"), "source": "profiles/r03_step_traffic.json"}
+    except Exception:
+        return None
+
+
 # ------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline(dev, dtype, budget_s=12.0):
     """The CPU oracle (oracle/cpu_ref.py: stock torch fp32 CPU ops, the reference's module graph) timed on the
@@ -225,10 +242,77 @@ def _timed(fn, warm, reps):
     if os.environ.get("XR_BENCH_TRACE"):
         print("  timed: " + " ".join(f"{t:.2f}" for t in ts), file=sys.stderr, flush=True)
     ts.sort()
-    return ts[len(ts) // 2], out
+    med = ts[len(ts) // 2]
+    if dist.is_initialized() and dist.get_world_size() > 1:   # data-parallel form: every call held the all-reduce; slowest rank counts
+        t = torch.tensor([med], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        med = float(t.item())
+    return med, out
 
 
-def secondary_workloads(dev, c4_batch=256, c3_batch=128):
+def cpu_secondary(kind, budget_s=10.0):
+    """CPU baseline of a secondary workload: the oracle's restatement of the same step -- forward, every
+    (loss_k, theta_k) gradient pair at pre-step weights -- on the host cores at N = 4 (C1: the configuration itself; C3 / C4:
+    scaled per image), bounded to ~budget_s; C5: the vectorised numpy restatement on a 1e5-pair sample."""
+    import numpy as np
+    from oracle import cpu_ref as R
+    from oracle import detgen as G
+    from xrface.model import FSRnet, model_irse
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    n = 4
+    if kind == "C5":
+        P = 100_000
+        e1, e2, same = G.synth_pairs(P, 512, seed=0)
+        fold = np.random.RandomState(0).randint(0, 10, P)
+        folds = [(np.where(fold != f)[0], np.where(fold == f)[0]) for f in range(10)]
+        thr = np.arange(0, 12000, 3)
+        t0, reps = time.perf_counter(), 0
+        while True:
+            R.calculate_roc(thr, e1, e2, same, folds)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s / 2 or reps >= 20:
+                break
+        el = (time.perf_counter() - t0) / reps
+        return {"value": round(P / el, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
+                "sample": f"numpy restatement of pair distances + 4000-threshold / 10-fold ROC on {P} pairs, {reps} calls of {el:.2f}s "
+                          "(numpy: one thread for the sweep, BLAS-free)"}
+    hr = G.synth_faces(n, 112, seed=1)
+    lr = G.synth_lr_from_hr(hr)
+    sds = {k: G.det_state_dict(m.state_dict()) for k, m in (("coarse", FSRnet.Course_SR_Network()), ("prior", FSRnet.Prior_Estimation_Network()),
+                                                           ("encoder", FSRnet.Fine_SR_Encoder()), ("decoder", FSRnet.Fine_SR_Decoder()))}
+    if kind == "C1":
+        fn = lambda: R.coarse_step_grads(sds["coarse"], lr, hr)
+        what = "Course_SR_Network fwd+bwd of 12*mse97"
+    elif kind == "C3":
+        hm = G.synth_heatmap(n, 28, 97, 1.3, seed=2)
+        par = G.synth_parsing(n, 28, 11, seed=2)
+        fn = lambda: R.fhn_step_grads(sds, lr, hr, hm, par)
+        what = "root FHN forward + the four (loss_k, theta_k) gradient pairs"
+    else:
+        irsd = [G.det_state_dict(model_irse.IR_SE_50([112, 112]).state_dict(), seed) for seed in (1, 2, 3)]
+        fn = lambda: R.c4_step_grads(sds, irsd[0], irsd[1], irsd[2], lr, hr)
+        what = "FHN -> IR-SE-50 student + assistant vs frozen teacher, residual-KD gradients"
+    fn()   # warm-up
+    t0, reps = time.perf_counter(), 0
+    while True:
+        fn()
+        reps += 1
+        if time.perf_counter() - t0 > budget_s or reps >= 50:
+            break
+    el = time.perf_counter() - t0
+    return {"value": round(n * reps / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{what}, fp32, N={n}/step, {reps} steps in {el:.1f}s"}
+
+
+def secondary_workloads(dev, c4_batch=256, c3_batch=128, world=1, rank=0, cpu_legs=True):
+    """world > 1 (BASELINE configs[2], [3]: the multi-GPU configurations): only C4 and C3, in their data-parallel form -- one
+    BucketedAllReduce per flat gradient buffer, buckets launched from the gradient hooks, waited for before the optimizer
+    updates; EVERY rank runs them (they hold collectives); times are the max over ranks."""
     import numpy as np
     import xrface
     from xrface import parallel, steps
@@ -257,19 +341,37 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
         opts = [parallel.FusedRMSprop(flats[0], lr=1e-5, alpha=0.99, weight_decay=1e-5),
                 parallel.FusedRMSprop(flats[1], lr=1e-4, alpha=0.99, weight_decay=1e-5),
                 parallel.FusedRMSprop(flats[2], lr=1e-4, alpha=0.99, weight_decay=1e-5)]
-        hr, _ = synth_batch(c4_batch, dev, 11)
+        reds = None
+        if world > 1:     # identical replicas (rank-0 broadcast lands in the flat buffers), one reducer per flat gradient buffer
+            for m_ in (*fhn.values(), student, assistant, teacher):
+                parallel.broadcast_module(m_)
+            reds = [parallel.BucketedAllReduce(f_) for f_ in flats]
+        hr, _ = synth_batch(c4_batch, dev, 11 + 97 * rank)
         lr = synth_lr(hr)
-        ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts), 3, 7)
+        ms, res = _timed(lambda: steps.c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts, reducers=reds), 3, 7)
         (sl, al), _ = res
-        tf = C4_STEP_GFLOP * c4_batch / ms            # GFLOP per ms = TFLOP/s
-        out.append({"workload": "C4 (BASELINE configs[3], per-GPU shape): root FHN (trainable) -> IR-SE-50 student + assistant vs frozen "
-                                "IR-SE-50 teacher on hr, residual-KD MSE losses, RMSprop x3, Dropout on, 112x112",
-                    "per_gpu_batch": c4_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c4_batch / ms * 1e3, 1),
-                    "algorithmic_tflop_per_step": round(C4_STEP_GFLOP * c4_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
-                    "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "student_loss": round(float(sl), 5),
-                    "assistant_loss": round(float(al), 5)})
-        del fhn, student, assistant, teacher, flats, opts, res
+        if world > 1:
+            for f_ in flats:      # replicas must still agree after ten averaged-gradient steps
+                chk = f_.flat[:4096].clone()
+                dist.broadcast(chk, 0)
+                assert torch.equal(chk, f_.flat[:4096]), "C4 replicas diverged: gradient all-reduce is broken"
+        tf = C4_STEP_GFLOP * c4_batch / ms            # GFLOP per ms = TFLOP/s (per GPU)
+        ent = {"workload": "C4 (BASELINE configs[3], per-GPU shape): root FHN (trainable) -> IR-SE-50 student + assistant vs frozen "
+                           "IR-SE-50 teacher on hr, residual-KD MSE losses, RMSprop x3, Dropout on, 112x112"
+                           + (", data parallel: three bucketed gradient all-reduces inside the step" if world > 1 else ""),
+               "n_gpus": world, "per_gpu_batch": c4_batch, "dtype": "bf16", "ms_per_step": round(ms, 2),
+               "images_per_s": round(c4_batch * world / ms * 1e3, 1),
+               "algorithmic_tflop_per_step": round(C4_STEP_GFLOP * c4_batch * world / 1e3, 2), "achieved_tflops": round(tf * world, 1),
+               "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "student_loss": round(float(sl), 5),
+               "assistant_loss": round(float(al), 5)}
+        rf = step_roofline("c4", ms, c4_batch)
+        if rf is not None:
+            ent["roofline"] = rf
+        out.append(ent)
+        del fhn, student, assistant, teacher, flats, opts, res, reds
         torch.cuda.empty_cache()
+        if world == 1 and cpu_legs:
+            ent["cpu_baseline"] = cpu_secondary("C4")
     work.append(("C4", w_c4))
 
     def w_c3():
@@ -277,19 +379,37 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
         fhn = mk_fhn()
         flats = {k: parallel.FlatParams(fhn[k].parameters()) for k in fhn}
         opts = {k: parallel.FusedRMSprop(flats[k], lr=1e-5, alpha=0.99, weight_decay=1e-5) for k in fhn}
-        hr, _ = synth_batch(c3_batch, dev, 12)
+        reds = None
+        if world > 1:
+            for m_ in fhn.values():
+                parallel.broadcast_module(m_)
+            reds = {k: parallel.BucketedAllReduce(flats[k]) for k in fhn}
+        hr, _ = synth_batch(c3_batch, dev, 12 + 97 * rank)
         lr = synth_lr(hr)
         hm = torch.rand(c3_batch, 28, 28, device=dev)
         par = torch.randint(0, 11, (c3_batch, 1, 28, 28), device=dev)
-        ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts), 3, 7)
+        ms, res = _timed(lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts, reducers=reds), 3, 7)
+        if world > 1:
+            for f_ in flats.values():
+                chk = f_.flat[:4096].clone()
+                dist.broadcast(chk, 0)
+                assert torch.equal(chk, f_.flat[:4096]), "C3 replicas diverged: gradient all-reduce is broken"
         tf = 3.0 * FHN_FWD_GFLOP * c3_batch / ms
-        out.append({"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
-                                "parsing losses, per-network gradients, RMSprop x4",
-                    "per_gpu_batch": c3_batch, "dtype": "bf16", "ms_per_step": round(ms, 2), "images_per_s": round(c3_batch / ms * 1e3, 1),
-                    "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch / 1e3, 2), "achieved_tflops": round(tf, 1),
-                    "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)})
-        del fhn, flats, opts, res
+        ent = {"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
+                           "parsing losses, per-network gradients, RMSprop x4"
+                           + (", data parallel: four bucketed gradient all-reduces inside the step" if world > 1 else ""),
+               "n_gpus": world, "per_gpu_batch": c3_batch, "dtype": "bf16", "ms_per_step": round(ms, 2),
+               "images_per_s": round(c3_batch * world / ms * 1e3, 1),
+               "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch * world / 1e3, 2), "achieved_tflops": round(tf * world, 1),
+               "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+        rf = step_roofline("c3", ms, c3_batch)
+        if rf is not None:
+            ent["roofline"] = rf
+        out.append(ent)
+        del fhn, flats, opts, res, reds
         torch.cuda.empty_cache()
+        if world == 1 and cpu_legs:
+            ent["cpu_baseline"] = cpu_secondary("C3")
     work.append(("C3", w_c3))
 
     def w_sr_perceptual_step():
@@ -329,7 +449,8 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
                     "images_per_s": round(nsr / ms_g * 1e3, 1), "achieved_tflops": round(sr_gf * nsr / ms_g, 1)})
         del nets, bb, flats, opts, gs
         torch.cuda.empty_cache()
-    work.append(("SR perceptual step", w_sr_perceptual_step))
+    if world == 1:
+        work.append(("SR perceptual step", w_sr_perceptual_step))
 
     def w_c2_parity_mode():
         # ---- C2 in the fp32 parity mode: the headline step in the mode that meets the 1e-3 embedding tolerance
@@ -352,7 +473,8 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
                     "images_per_s": round(256 / ms * 1e3, 1)})
         del net, flat, opt
         torch.cuda.empty_cache()
-    work.append(("C2 parity mode", w_c2_parity_mode))
+    if world == 1:
+        work.append(("C2 parity mode", w_c2_parity_mode))
 
     def w_c1():
         # ---- C1: coarse net, batch 4, fp32 parity mode (the reference's CPU-runnable case); eager launches and one HIP-graph replay
@@ -383,7 +505,10 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
                     "ms_per_step": round(ms_g, 3), "images_per_s": round(4 / ms_g * 1e3, 1)})
         del net, opt, flat, gs
         xrface.set_compute_dtype(torch.bfloat16)
-    work.append(("C1", w_c1))
+        if cpu_legs:
+            out[-1]["cpu_baseline"] = cpu_secondary("C1")
+    if world == 1:
+        work.append(("C1", w_c1))
 
     def w_c5():
         # ---- C5: P = 1e6 pair distances + 4000-threshold / 10-fold ROC
@@ -405,8 +530,13 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128):
         roc_ms = (time.perf_counter() - t0) * 1e3
         out.append({"workload": "C5 (BASELINE configs[4]): 1M-pair 512-d squared-L2 distances + 4000-threshold / 10-fold ROC",
                     "pairs": P, "pairdist_ms": round(ms, 3), "pairdist_gb_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
-                    "calculate_roc_ms": round(roc_ms, 2), "accuracy": round(float(acc), 4)})
-    work.append(("C5", w_c5))
+                    "calculate_roc_ms": round(roc_ms, 2), "accuracy": round(float(acc), 4),
+                    "pairs_per_s": round(P / (roc_ms * 1e-3), 1)})
+        del e1, e2
+        if cpu_legs:
+            out[-1]["cpu_baseline"] = cpu_secondary("C5")
+    if world == 1:
+        work.append(("C5", w_c5))
 
     for name, fn in work:
         try:
@@ -427,6 +557,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--c4-batch", type=int, default=256, help="per-GPU batch of the secondary C4 step")
+    ap.add_argument("--c3-batch", type=int, default=128, help="per-GPU batch of the secondary C3 step")
     ap.add_argument("--all-sites", action="store_true", help="report every conv launch site in `kernels`, not the top 8")
     args = ap.parse_args()
 
@@ -559,17 +691,25 @@ def main():
             line["cpu_baseline"], emb_err = cpu_baseline(dev, dtype)
             line["embedding_rel_l2_vs_cpu"] = round(emb_err[0], 6)
             line["embedding_rel_l2_vs_cpu_fp32_parity_mode"] = round(emb_err[1], 7)
-        if world == 1 and not args.no_secondary and bf:
-            del model, flat, opt, reducer
-            torch.cuda.empty_cache()
-            try:
-                with torch.cuda.stream(hp):      # same stream set-up as the headline: the side work yields to the critical path
-                    line["secondary"] = secondary_workloads(dev)
-                torch.cuda.current_stream(dev).wait_stream(hp)
-            except Exception as e:   # noqa: BLE001 -- the headline line is printed whatever happens to the extras
-                line["secondary"] = [{"error": f"{type(e).__name__}: {e}"[:300]}]
+    else:
+        line = None
+    if not args.no_secondary and bf:
+        # N > 1: EVERY rank runs the data-parallel C4 / C3 steps (they hold the gradient all-reduces); rank 0 reports them
+        del model, flat, opt, reducer
+        torch.cuda.empty_cache()
+        try:
+            with torch.cuda.stream(hp):      # same stream set-up as the headline: the side work yields to the critical path
+                sec = secondary_workloads(dev, c4_batch=args.c4_batch, c3_batch=args.c3_batch, world=world, rank=rank,
+                                          cpu_legs=not args.no_cpu_baseline)
+            torch.cuda.current_stream(dev).wait_stream(hp)
+        except Exception as e:   # noqa: BLE001 -- the headline line is printed whatever happens to the extras
+            sec = [{"error": f"{type(e).__name__}: {e}"[:300]}]
+        if line is not None:
+            line["secondary"] = sec
+    if line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -606,11 +606,12 @@ __global__ __launch_bounds__(NT) void roc_hist_kernel(const float* __restrict__ 
 // threshold; the fold means are summed in fold order and divided by F like numpy.mean(axis=0).  All rates are IEEE double
 // divisions of the same integers the host formula divides: bit-identical to the numpy evaluation.
 constexpr int RT = 1024;
+constexpr int ROC_MAX_FOLDS = 256;   // the reference's default is nrof_folds = 50 (utils/utils.py:26)
 __global__ __launch_bounds__(RT) void roc_sweep_kernel(unsigned long long* __restrict__ hist, int T, int F, double* __restrict__ mean_tpr,
                                                        double* __restrict__ mean_fpr, double* __restrict__ acc,
                                                        int* __restrict__ best_idx) {
   __shared__ long long s_part[RT];
-  __shared__ long long s_tot[64];     // [f][lab], F <= 32
+  __shared__ long long s_tot[2 * ROC_MAX_FOLDS];     // [f][lab]
   __shared__ long long s_bv[RT / 64];
   __shared__ int s_bi[RT / 64];
   __shared__ int s_best;
@@ -973,7 +974,7 @@ extern "C" int xr_roc_hist(const float* dist, const uint8_t* issame, const int32
 extern "C" int xr_roc_sweep(unsigned long long* hist, int T, int F, double* mean_tpr, double* mean_fpr, double* acc, int* best_idx,
                             void* stream) {
   XR_CHECK_ARG(hist && mean_tpr && mean_fpr && acc && best_idx, "xr_roc_sweep: null pointer");
-  XR_CHECK_ARG(T > 0 && T <= 16000 && F >= 2 && F <= 32, "xr_roc_sweep: needs 0 < T <= 16000 thresholds and 2 <= F <= 32 folds");
+  XR_CHECK_ARG(T > 0 && T <= 16000 && F >= 2 && F <= ROC_MAX_FOLDS, "xr_roc_sweep: needs 0 < T <= 16000 thresholds and 2 <= F <= 256 folds");
   hipLaunchKernelGGL(roc_sweep_kernel, dim3(1), dim3(RT), 0, (hipStream_t)stream, hist, T, F, mean_tpr, mean_fpr, acc, best_idx);
   XR_CHECK_LAUNCH("xr_roc_sweep");
   return XR_OK;

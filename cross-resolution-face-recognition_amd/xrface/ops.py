@@ -145,14 +145,22 @@ def _direct_done(p):
 # main stream: their MFMA work fills the ramp-up / tail bubbles and the idle CUs of the main-stream kernels and overlaps
 # the HBM-bound elementwise passes.  The main stream re-joins at the end of the backward pass (autograd engine callback)
 # and before any gradient bucket is handed to RCCL.
-_side = {"stream": None, "dev": None, "ev": None, "pending": False, "cb": False}
+_side = {"stream": None, "dev": None, "ev": None, "seq": 0, "joined": {}, "cb": False}
 
 
 def join_side_stream():
-    """Make the current stream wait for the weight-gradient side stream (no-op when nothing is pending)."""
-    if _side["pending"]:
-        torch.cuda.current_stream(_side["dev"]).wait_stream(_side["stream"])
-        _side["pending"] = False
+    """Make the CURRENT stream wait for everything launched on the weight-gradient side stream so far (no-op when this stream
+    already joined the latest side launch).  Bookkeeping is per joining stream: with lockstep chains (steps.c4_step / kd_step)
+    several streams feed the one side stream, and a gradient bucket launched from one chain's stream must wait for that chain's
+    weight gradients even if another chain's stream joined in between."""
+    seq = _side["seq"]
+    if not seq:
+        return
+    cur = torch.cuda.current_stream(_side["dev"])
+    key = cur.cuda_stream
+    if _side["joined"].get(key) != seq:
+        cur.wait_stream(_side["stream"])
+        _side["joined"][key] = seq
 
 
 def _join_cb():
@@ -164,6 +172,7 @@ def _side_fork(dev):
     """The side stream, made to wait for all work enqueued so far on the current stream (one reused event)."""
     if _side["stream"] is None or _side["dev"] != dev:
         _side["stream"], _side["dev"], _side["ev"] = torch.cuda.Stream(dev), dev, torch.cuda.Event()
+        _side["seq"], _side["joined"] = 0, {}
     ev = _side["ev"]
     ev.record()
     _side["stream"].wait_event(ev)
@@ -175,7 +184,7 @@ def _side_done(side, tensors):
     kernels ran; the main stream re-joins at the end of the backward pass."""
     for t in tensors:
         t.record_stream(side)
-    _side["pending"] = True
+    _side["seq"] += 1
     if not _side["cb"]:
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join_cb)

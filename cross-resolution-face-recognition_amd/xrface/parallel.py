@@ -115,6 +115,7 @@ class BucketedAllReduce:
         self._count = [0] * len(flat.params)
         self._late = None
         self.launch_order = []                     # bucket indices in the order they were launched this step (tests)
+        self.last_launch_order, self.last_early = [], 0
         # force: run the collectives even in a one-rank group (tests: the RCCL path on a single GPU)
         self.enabled = self.world > 1 or (force and dist.is_initialized())
         if self.enabled and overlap:
@@ -162,6 +163,7 @@ class BucketedAllReduce:
         """Launch any bucket whose parameters never produced a gradient this step, then wait for all."""
         if not self.enabled:
             return
+        self.last_early = len(self.launch_order)   # buckets that went out from the gradient hooks, during backward
         for b in range(len(self.buckets)):
             if not self._launched[b]:
                 self._launch(b)

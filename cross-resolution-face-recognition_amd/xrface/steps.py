@@ -27,6 +27,7 @@ def _assign_grads(params, grads):
             # into it in place (autograd then returns None); a tensor autograd did return is added into the view
             if g is not None:
                 p.grad.add_(g)
+                p.__dict__["_xr_touched"] = True   # (autograd.grad fires no post-accumulate hook: the fused optimizers' skip mask)
             continue
         p.grad = g  # None stays None: stock optimizers then skip the parameter (incl. weight decay)
 
@@ -57,6 +58,18 @@ def _zero_grads(modules, optimizers=None):
                 p.grad = None
 
 
+def _finish_reducers(reducers):
+    """Data-parallel form of a step: every gradient is in its flat buffer (the caller's stream has joined the side /
+    lockstep streams) -> launch the buckets that did not go out from the gradient hooks, wait for all of them.  ``reducers``:
+    one parallel.BucketedAllReduce per flat buffer (iterable / dict / None)."""
+    if reducers is None:
+        return
+    ops.join_side_stream()
+    for r in (reducers.values() if isinstance(reducers, dict) else reducers):
+        if r is not None:
+            r.finish()
+
+
 def fhn_step(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
     """nets: dict(coarse, prior, encoder, decoder).  Returns (losses dict, outputs dict); .grad of each
     sub-network holds d L_k / d theta_k.  If ``optimizers`` (same keys) is given they are stepped."""
@@ -82,12 +95,14 @@ def fhn_step(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
     return {k: v.detach() for k, v in losses.items()}, outs
 
 
-def fhn_step_fused(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
+def fhn_step_fused(nets, lr_img, hr_img, heatmap, parsing, optimizers=None, reducers=None):
     """fhn_step's four (loss_k, theta_k) gradients from ONE backward pass.  The map is linear: the encoder and the decoder
     both take 10 * d pix, the prior takes 1 * d pix + d landmark + d parsing, the coarse net only d(12 * mse97(coarse, hr))
     -- so the prior / encoder see a detached coarse image, the pixel loss is back-propagated once with weight 10 and the
     prior's branch re-scales it by 0.1 (ops.grad_scale).  3x forward FLOPs (SURVEY 8d's count for C3) instead of the five
-    partial traversals of the literal form; results agree with fhn_step to rounding (tests/test_gpu_models.py)."""
+    partial traversals of the literal form; results agree with fhn_step to rounding (tests/test_gpu_models.py).
+    ``reducers`` (data parallel, BASELINE configs[2]): parallel.BucketedAllReduce objects over the flat buffers of ``nets``;
+    their buckets go out from the gradient hooks during backward and are waited for before the optimizers step."""
     mse97, lmk_loss, ce2d = MSELossFunc(), MSELoss_Landmark(), CrossEntropyLoss2d()
     order = ("coarse", "encoder", "prior", "decoder")
     _zero_grads([nets[k] for k in order], optimizers)
@@ -99,6 +114,7 @@ def fhn_step_fused(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
     pix = mse97(sr, hr_img)
     l_coarse, l_lmk, l_par = 12.0 * mse97(coarse, hr_img), lmk_loss(lmk, heatmap), ce2d(par, parsing)
     (l_coarse + 10.0 * pix + l_lmk + l_par).backward()
+    _finish_reducers(reducers)      # BASELINE configs[2]: gradient all-reduce between backward and the updates
     if optimizers is not None:
         for k in order:
             optimizers[k].step()
@@ -109,16 +125,19 @@ def fhn_step_fused(nets, lr_img, hr_img, heatmap, parsing, optimizers=None):
     return losses, outs
 
 
-def gan_step(model, lr_img, hr_img, heatmap, parsing, optimizers=None):
+def gan_step(model, lr_img, hr_img, heatmap, parsing, optimizers=None, criterion_mmd=None):
     """Face_Hallucination_sub_Net.py:218-247 as written, on OverallNetwork_GAN (224x224 only, model/FSRnet.py:468) with the
     discriminator terms kept: L_disc = -MMD(emb1, emb2) -> discriminator; L_coarse = 12*mse97(coarse, hr) -> coarse;
     L_enc = 10*mse97(sr, hr) - L_disc -> encoder; L_prior = -L_disc + mse97(sr, hr) + lmk + CE -> prior;
-    L_dec = 10*mse97(sr, hr) -> decoder.  MMD is undefined upstream (build-defined, loss/loss.py:MMD; parity unpinned).
-    ``optimizers``: dict(disc, coarse, encoder, prior, decoder)."""
-    from .loss.loss import MMD
+    L_dec = 10*mse97(sr, hr) -> decoder.  ``criterion_mmd(emb1, emb2)`` is the reference's ``criterion_mmd`` (:216); its
+    class is undefined upstream (:25), so the default is the build-defined Gaussian-kernel MMD (loss/loss.py:MMD; parity
+    unpinned) -- with any pinned distance injected (tests: nn.MSELoss) the whole loss -> sub-network map is pinned by
+    tests/golden/gan_step.npz.  ``optimizers``: dict(disc, coarse, encoder, prior, decoder)."""
+    if criterion_mmd is None:
+        from .loss.loss import MMD as criterion_mmd
     mse97, lmk_loss, ce2d = MSELossFunc(), MSELoss_Landmark(), CrossEntropyLoss2d()
     sr, coarse, lmk, par, e1, e2 = model(lr_img, hr_img)
-    l_disc = -MMD(e1, e2)
+    l_disc = -criterion_mmd(e1, e2)
     pix = mse97(sr, hr_img)
     losses = {
         "disc": l_disc,
@@ -184,7 +203,7 @@ class _Landmark1(torch.nn.Module):
 _LMK1 = _Landmark1()
 
 
-def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_optimizer=None, taps=(2, 6, 20, 23)):
+def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_optimizer=None, taps=(2, 6, 20, 23), reducers=None):
     """Residual knowledge distillation: student matches the frozen teacher's embedding; the assistant learns the
     residual (teacher - student) at the four stage taps and the embedding."""
     crit = MSELoss()
@@ -212,6 +231,7 @@ def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_op
     _pair_grads(a_loss, assistant, retain=False)
     if lock:
         lockstep.join(x.device, 2)
+    _finish_reducers(reducers)
     if student_optimizer is not None:
         student_optimizer.step()
     if assistant_optimizer is not None:
@@ -219,7 +239,7 @@ def kd_step(teacher, student, assistant, x, student_optimizer=None, assistant_op
     return (s_loss.detach(), a_loss.detach()), [v.detach() for v in s], [v.detach() for v in a], [v.detach() for v in t]
 
 
-def c4_step(fhn, student, assistant, teacher, lr_img, hr_img, optimizers=None, taps=(2, 6, 20, 23)):
+def c4_step(fhn, student, assistant, teacher, lr_img, hr_img, optimizers=None, taps=(2, 6, 20, 23), reducers=None):
     """BASELINE configs[3]: the two halves of the system composed into one training step.
     sr = FHN(lr) with the four generators composed as SUPER_RESOLUTION/train_FHN.py:274-279; the IR-SE-50 student and
     assistant both see ``sr``, the frozen eval-mode IR-SE-50 teacher sees ``hr`` (5-output form distill_main.py:59 unpacks,
@@ -229,6 +249,10 @@ def c4_step(fhn, student, assistant, teacher, lr_img, hr_img, optimizers=None, t
     The two parameter sets are disjoint and the assistant's targets / input are detached, so ONE backward pass of
     student_loss + assistant_loss yields exactly the two pair gradients (and is safe with FlatParams(direct=True)).
     ``fhn``: dict(coarse, prior, encoder, decoder); ``optimizers`` (optional): iterable / dict of optimizers, all stepped.
+    ``reducers`` (data parallel, BASELINE configs[3]: "8 MI355X DDP"): one parallel.BucketedAllReduce per flat gradient buffer
+    (FHN, student, assistant).  Buckets are launched from the gradient hooks on the stream of the chain that produced them (each
+    launch first joins the weight-gradient side stream); after backward() the caller's stream joins the lockstep chains, the
+    remaining buckets go out, and every all-reduce is waited for before the optimizers read the gradients.
     Returns ((student_loss, assistant_loss), outputs dict)."""
     crit = MSELoss()
     teacher.eval()
@@ -259,6 +283,7 @@ def c4_step(fhn, student, assistant, teacher, lr_img, hr_img, optimizers=None, t
     (s_loss + a_loss).backward()
     if lock:
         lockstep_join(sr.device, 2)
+    _finish_reducers(reducers)
     if optimizers is not None:
         for o in (optimizers.values() if isinstance(optimizers, dict) else optimizers):
             o.step()

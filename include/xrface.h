@@ -374,7 +374,7 @@ int xr_roc_hist(const float* dist, const uint8_t* issame, const int32_t* fold_id
 /* K-fold sweep over that histogram on the device (utils/utils.py:51-83; one workgroup): hist is overwritten with its prefix
  * sums over j; per fold f the threshold index maximising the accuracy of the OTHER folds (first maximum, numpy.argmax) ->
  * best_idx[f], the fold's own accuracy at it -> acc[f] (fp64); mean over folds of tpr / fpr at every threshold -> mean_tpr[T],
- * mean_fpr[T] (fp64; bit-identical to the numpy evaluation of the same integer counts).  2 <= F <= 32. */
+ * mean_fpr[T] (fp64; bit-identical to the numpy evaluation of the same integer counts).  2 <= F <= 256 (the reference default is 50). */
 int xr_roc_sweep(unsigned long long* hist, int T, int F, double* mean_tpr, double* mean_fpr, double* acc, int* best_idx, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -442,9 +442,14 @@ def calculate_roc(thresholds, e1, e2, issame, folds):
     """calculate_roc (utils/utils.py:26-87) with the fold index arrays given explicitly
     (the reference draws them from an unseeded sklearn KFold) and the unused
     O(P^2 log P) ``margin_list`` (:47-49) dropped.  ``folds`` = list of (train_idx, test_idx)."""
+    return calculate_roc_from_dist(thresholds, pair_dist(e1, e2), issame, folds)
+
+
+def calculate_roc_from_dist(thresholds, dist, issame, folds):
+    """The K-fold part of calculate_roc (utils/utils.py:51-87) on given distances."""
     thresholds = np.asarray(thresholds)
     issame = np.asarray(issame)
-    dist = pair_dist(e1, e2)
+    dist = np.asarray(dist)
     k, t = len(folds), len(thresholds)
     tprs, fprs = np.zeros((k, t)), np.zeros((k, t))
     acc, best = np.zeros(k), np.zeros(k)
@@ -531,6 +536,33 @@ def fhn_step_grads(sds, lr_img, hr_img, heatmap, parsing):
     }
     grads = {k: grads_of(losses[k], sds[k], retain=True) for k in ("coarse", "encoder", "prior", "decoder")}
     outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach())
+    return {k: v.detach() for k, v in losses.items()}, outs, grads
+
+
+def gan_step_grads(sd, lr_img, hr_img, heatmap, parsing, dist=None):
+    """Face_Hallucination_sub_Net.py:218-247 on OverallNetwork_GAN (224x224) at pre-step weights: one forward, then
+      L_disc  = -dist(emb1, emb2)                                   -> _discriminator
+      L_coarse = 12 * mse97(coarse, hr)                             -> _coarse_sr_network
+      L_enc   = 10 * mse97(sr, hr) - L_disc                         -> _fine_sr_encoder
+      L_prior = -L_disc + mse97(sr, hr) + landmark + CE             -> _prior_estimation_network
+      L_dec   = 10 * mse97(sr, hr)                                  -> _fine_sr_decoder
+    ``dist`` stands in for the reference's undefined ``MMD`` import (:25); default F.mse_loss.
+    Returns (losses, outputs, {subnet: {param name without the sub-network prefix: grad or None}})."""
+    dist = dist or F.mse_loss
+    sdg = with_grad(sd)
+    sr, coarse, lmk, par, e1, e2, _ = gan_forward(sdg, lr_img, hr_img, train=True)
+    l_disc = -dist(e1, e2)
+    pix = mse97(sr, hr_img)
+    losses = {"disc": l_disc, "coarse": 12.0 * mse97(coarse, hr_img), "encoder": 10.0 * pix - l_disc,
+              "prior": -l_disc + pix + landmark_loss(lmk, heatmap) + nll2d(par, parsing), "decoder": 10.0 * pix}
+    prefix = {"disc": "_discriminator.", "coarse": "_coarse_sr_network.", "encoder": "_fine_sr_encoder.",
+              "prior": "_prior_estimation_network.", "decoder": "_fine_sr_decoder."}
+    grads = {}
+    for k, pre in prefix.items():
+        sub = {n[len(pre):]: v for n, v in sdg.items() if n.startswith(pre)}
+        grads[k] = grads_of(losses[k], sub, retain=True)
+    outs = dict(sr=sr.detach(), coarse=coarse.detach(), landmark=lmk.detach(), parsing=par.detach(), emb1=e1.detach(),
+                emb2=e2.detach())
     return {k: v.detach() for k, v in losses.items()}, outs, grads
 
 

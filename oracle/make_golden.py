@@ -443,6 +443,47 @@ def sec_gan(keys, t0):
     print(f"[golden] gan224 ok ({time.time() - t0:.1f}s)")
 
 
+def sec_gan_step(keys, t0):
+    # ------------------------------------------------------------------ adversarial loss -> optimizer map (a16 / f4)
+    # Face_Hallucination_sub_Net.py:218-247 on the reference's own OverallNetwork_GAN @224; the undefined MMD import (:25) is
+    # replaced by F.mse_loss(emb1, emb2) on BOTH sides -- the five (loss_k, theta_k) gradient sets are what is pinned.
+    fsr = ref_import("model.FSRnet")
+    loss_mod = ref_import("loss.loss")
+    st = {}
+    n = 3       # (train-mode BatchNorm1d over a batch of 2 is degenerate: outputs +-gamma)
+    hr = G.synth_faces(n, 224, seed=1, start=900)
+    lr = G.synth_lr_from_hr(hr)
+    hm = G.synth_heatmap(n, 56, 97, 1.3, seed=5)
+    par = G.synth_parsing(n, 56, 11, seed=5)
+    net = fsr.OverallNetwork_GAN()
+    sd = load_det(net, 9)
+    net.train()
+    sr, coarse, lmk, prs, e1, e2 = net(lr, hr)
+    mse = loss_mod.MSELossFunc()
+    gan_loss = -F.mse_loss(e1, e2)
+    pix = mse(sr, hr)
+    losses = dict(disc=gan_loss, coarse=12.0 * mse(coarse, hr), encoder=10.0 * pix - gan_loss,
+                  prior=-gan_loss + pix + loss_mod.MSELoss_Landmark()(lmk, hm) + 1.0 * loss_mod.CrossEntropyLoss2d()(prs, par),
+                  decoder=10.0 * pix)
+    subs = dict(disc=net._discriminator, coarse=net._coarse_sr_network, encoder=net._fine_sr_encoder,
+                prior=net._prior_estimation_network, decoder=net._fine_sr_decoder)
+    l2, outs2, g2 = R.gan_step_grads(sd, lr, hr, hm, par)
+    for nm, b_ in (("sr", sr), ("coarse", coarse), ("landmark", lmk), ("parsing", prs), ("emb1", e1), ("emb2", e2)):
+        close(outs2[nm], b_, "gan_step " + nm, 5e-4)
+        pack(st, "out/" + nm, b_)
+    keep = dict(disc=("conv_input.weight", "bn_mid.weight", "fc.weight", "fc.bias", "bn_end.weight"),
+                coarse=("conv_input.weight", "residual.2.conv1.weight", "conv_mid.weight"),
+                encoder=("conv_input.weight", "conv_end.weight", "relu.weight", "residual.0.conv1.weight"),
+                prior=("conv.weight", "fc.weight", "fc_landmark.bias", "hg.hg.0.3.1.conv2.weight", "residual.1.conv1.weight"),
+                decoder=("conv_input.weight", "deconv.weight", "deconv.bias", "conv_out.weight", "bn_mid.weight"))
+    for k in ("disc", "coarse", "encoder", "prior", "decoder"):
+        close(l2[k], losses[k], f"gan_step loss {k}", 1e-5)
+        st[f"loss/{k}"] = np.float64(losses[k].item())
+        compare_grads(grads_ref(losses[k], subs[k], retain=True), g2[k], f"gan_step {k}", st, f"{k}/", keep[k])
+    np.savez_compressed(os.path.join(OUT, "gan_step.npz"), **st)
+    print(f"[golden] gan_step ok ({time.time() - t0:.1f}s)")
+
+
 SECTIONS = {}   # filled below main's helpers (name -> function), in generation order
 
 
@@ -517,7 +558,7 @@ def main(argv):
 
 
 SECTIONS.update(fsrnet_root=sec_fsrnet_root, fsrnet_sr=sec_fsrnet_sr, irse=sec_irse, resnet_kd=sec_resnet_kd,
-                losses_roc=sec_losses_roc, c4=sec_c4, gan=sec_gan, loader=sec_loader)
+                losses_roc=sec_losses_roc, c4=sec_c4, gan=sec_gan, gan_step=sec_gan_step, loader=sec_loader)
 
 if __name__ == "__main__":
     main(sys.argv[1:])

@@ -153,11 +153,11 @@ def test_ir_backbone_eval_and_train(tag, se):
     for k in ("2", "6", "20", "21", "22", "23"):
         check_against(st, f"{tag}/eval/tap{k}", feats[k], TOL)
     # train step, Dropout pinned off (p = 0) exactly like the fixture
+    # (through steps.teacher_step, the counterpart of train_teacher_model.py:189-202; no optimizer: gradients are inspected)
+    from xrface.steps import teacher_step
     net.train()
     net.output_layer[1].p = 0.0
-    out = net(x.to(DEV))
-    loss = CrossEntropyLoss()(out, tgt.to(DEV))
-    loss.backward()
+    loss, out = teacher_step(net, x.to(DEV), tgt.to(DEV), criterion=CrossEntropyLoss())
     check_against(st, f"{tag}/train/emb", out, TOL)
     assert abs(loss.item() - float(st[f"{tag}/train/loss"])) <= TOL * abs(float(st[f"{tag}/train/loss"]))
     g = grads_by_name(net)
@@ -172,6 +172,14 @@ def test_ir_backbone_eval_and_train(tag, se):
               "output_layer.4.running_mean"):
         check_against(st, f"{tag}/train/stats/{k}", new_sd[k], TOL)
     assert int(new_sd["input_layer.1.num_batches_tracked"]) == 1
+    # the same step with a stock optimizer (train_teacher_model.py:200-202: zero_grad / backward / step): p <- p - lr * grad
+    w_name = "body.23.res_layer.3.weight"
+    w0, g0 = net.get_parameter(w_name).detach().clone(), g[w_name].clone()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    loss2, _ = teacher_step(net, x.to(DEV), tgt.to(DEV), optimizer=opt, criterion=CrossEntropyLoss())
+    assert abs(loss2.item() - loss.item()) <= 1e-4 * abs(loss.item())
+    step_err = float(((w0 - net.get_parameter(w_name).detach()) / 0.1 - g0).abs().max() / g0.abs().max())
+    assert step_err < 5e-3, step_err
 
 
 def test_ir_dropout_mask_matches_oracle():
@@ -759,6 +767,46 @@ def test_overall_network_gan_224_matches_reference_fixture():
         outs = net(lr[:2].to(DEV), hr[:2].to(DEV))
     for nm, t in zip(("sr", "coarse", "landmark", "parsing", "emb1", "emb2"), outs):
         check_against(st, "eval/" + nm, t, TOL)
+
+
+def test_gan_step_adversarial_loss_map_matches_reference_fixture():
+    """Row f4 / a16 with the discriminator terms kept: steps.gan_step (Face_Hallucination_sub_Net.py:218-247) on
+    OverallNetwork_GAN at 224 x 224, N = 3, fp32 parity mode.  The reference's ``MMD`` import is undefined upstream, so the
+    fixture (tests/golden/gan_step.npz, generated from the reference's own OverallNetwork_GAN + loss classes) and this test
+    both inject nn.MSELoss-like ``criterion_mmd``: the five (loss_k, theta_k) pairs -- incl. the -L_disc terms that reach the
+    encoder and the prior through BOTH discriminator calls -- are pinned: six outputs, five losses, every kept gradient and
+    the .grad-is-None set of each sub-network."""
+    import xrface
+    from xrface.loss.loss import MSELoss
+    from xrface.model.FSRnet import OverallNetwork_GAN
+    from xrface.steps import gan_step
+    xrface.set_compute_dtype(torch.float32)
+    st = load_gold("gan_step.npz")
+    net, _ = load_det(OverallNetwork_GAN(), 9)
+    n = 3
+    hr = G.synth_faces(n, 224, seed=1, start=900)
+    lr = G.synth_lr_from_hr(hr)
+    hm = G.synth_heatmap(n, 56, 97, 1.3, seed=5)
+    par = G.synth_parsing(n, 56, 11, seed=5)
+    net.train()
+    losses, outs = gan_step(net, lr.to(DEV), hr.to(DEV), hm.to(DEV), par.to(DEV), criterion_mmd=MSELoss())
+    for nm in ("sr", "coarse", "landmark", "parsing", "emb1", "emb2"):
+        check_against(st, "out/" + nm, outs[nm], TOL)
+    subs = {"disc": net._discriminator, "coarse": net._coarse_sr_network, "encoder": net._fine_sr_encoder,
+            "prior": net._prior_estimation_network, "decoder": net._fine_sr_decoder}
+    for k, m in subs.items():
+        ref = float(st[f"loss/{k}"])
+        assert abs(losses[k].item() - ref) <= TOL * abs(ref), (k, losses[k].item(), ref)
+        _check_prefixed_grads(st, k + "/", m, GRAD_TOL)
+    # with stock optimizers: the step moves every sub-network that received a gradient and leaves the .grad-None parameters alone
+    opts = {k: torch.optim.RMSprop(m.parameters(), lr=5e-3, alpha=0.99, weight_decay=1e-5) for k, m in subs.items()}
+    before = {k: {n_: p_.detach().clone() for n_, p_ in m.named_parameters()} for k, m in subs.items()}
+    gan_step(net, lr.to(DEV), hr.to(DEV), hm.to(DEV), par.to(DEV), optimizers=opts, criterion_mmd=MSELoss())
+    for k, m in subs.items():
+        none_ref = set(st[k + "/none_grad_keys"].tolist())
+        for n_, p_ in m.named_parameters():
+            same = torch.equal(p_.detach(), before[k][n_])
+            assert same == (n_ in none_ref), (k, n_, same)
 
 
 def test_verify_step_matches_host_evaluation_of_the_same_embeddings():

@@ -535,6 +535,33 @@ def test_pairdist_and_roc_against_reference_fixture():
     assert np.array_equal(t1, tr) and np.array_equal(f1, fr) and a1 == ar and np.array_equal(b1, br)
 
 
+def test_calculate_roc_default_fold_count_matches_oracle():
+    """calculate_roc with the reference's DEFAULT nrof_folds = 50 (utils/utils.py:26) and with 200 folds: the device sweep
+    (xr_roc_sweep, up to 256 folds) against the oracle's numpy evaluation fed with the SAME distances and the same fold
+    membership.  The default call draws its folds from sklearn's KFold(shuffle=True) on the global numpy RNG exactly like the
+    reference -- pinned here with np.random.seed."""
+    from sklearn.model_selection import KFold
+    from xrface.utils.utils import calculate_roc, pair_dist
+    from oracle import cpu_ref as R
+    p = 3000
+    e1, e2, same = G.synth_pairs(p, 512, seed=3)
+    thresholds = np.arange(0, 12000, 3)
+    dist = pair_dist(e1, e2).cpu().numpy()
+    for folds_n in (50, 200):
+        np.random.seed(77)
+        folds = list(KFold(n_splits=folds_n, shuffle=True).split(np.arange(p)))
+        np.random.seed(77)
+        if folds_n == 50:
+            tpr, fpr, acc, best = calculate_roc(thresholds, e1, e2, same)            # default argument, internal KFold draw
+        else:
+            tpr, fpr, acc, best = calculate_roc(thresholds, e1, e2, same, nrof_folds=folds_n)
+        r_tpr, r_fpr, r_acc, r_best = R.calculate_roc_from_dist(thresholds, dist, same, folds)
+        assert best.shape == (folds_n,)
+        assert np.array_equal(tpr, r_tpr) and np.array_equal(fpr, r_fpr) and acc == r_acc and np.array_equal(best, r_best)
+    with pytest.raises(RuntimeError):
+        calculate_roc(thresholds, e1[:600], e2[:600], same[:600], nrof_folds=300)
+
+
 def test_arcface_head_against_fp64_restatement():
     """ArcFace is absent from the reference (parity unpinned): checked against the fp64 restatement in the oracle."""
     from oracle import cpu_ref as R

@@ -80,13 +80,41 @@ def _worker(rank, world, port, q):
         torch.cuda.synchronize()
         stats = torch.cat([b.float().reshape(-1) for n, b in net2.named_buffers() if n.endswith("running_mean")])
         res["irse"] = (flat2.flat.cpu().numpy(), early2, len(red2.buckets), stats.cpu().numpy())
+        # ---- (3) BASELINE configs[3] in its data-parallel form: steps.c4_step with one reducer per flat gradient buffer (FHN with
+        # its shared trunks signalling at nine sites, student, assistant), lockstep chains + weight-gradient side stream on
+        from xrface.model import FSRnet
+        from xrface.steps import c4_step
+        assert ops._cfg["lockstep"] == 1
+        torch.manual_seed(300 + rank)
+        fhn = {"coarse": FSRnet.Course_SR_Network().to(dev), "prior": FSRnet.Prior_Estimation_Network().to(dev),
+               "encoder": FSRnet.Fine_SR_Encoder().to(dev), "decoder": FSRnet.Fine_SR_Decoder().to(dev)}
+        student, assistant, teacher = (IR_SE_50([112, 112]).to(dev) for _ in range(3))
+        for p_ in teacher.parameters():
+            p_.requires_grad_(False)
+        for m in (*fhn.values(), student, assistant, teacher):
+            parallel.broadcast_module(m)
+        flats = [parallel.FlatParams([p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]),
+                 parallel.FlatParams(student.parameters_in_execution_order()),
+                 parallel.FlatParams(assistant.parameters_in_execution_order())]
+        opts = [parallel.FusedRMSprop(f_, lr=1e-5, alpha=0.99, weight_decay=1e-5) for f_ in flats]
+        reds = [parallel.BucketedAllReduce(f_, bucket_mb=mb, overlap=True) for f_, mb in zip(flats, (4.0, 24.0, 24.0))]
+        early3, losses3 = [], []
+        for step in range(3):
+            hr = torch.rand(2, 3, 112, 112, device=dev, generator=g) * 2 - 1
+            lr_ = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 7), size=(112, 112), mode="bilinear")
+            # (c4_step zeroes the gradients through the optimizers, finishes the reducers after backward + the lockstep join)
+            (sl, al), _ = c4_step(fhn, student, assistant, teacher, lr_, hr, optimizers=opts, reducers=reds)
+            early3.append([(list(r_.last_launch_order), r_.last_early) for r_ in reds])
+            losses3.append((float(sl), float(al)))
+        torch.cuda.synchronize()
+        res["c4"] = ([f_.flat.cpu().numpy() for f_ in flats], early3, [len(r_.buckets) for r_ in reds], losses3)
         q.put((rank, res))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1200)
 def test_two_ranks_on_one_gpu_stay_bit_identical():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -97,7 +125,7 @@ def test_two_ranks_on_one_gpu_stay_bit_identical():
     got = {}
     try:
         for _ in range(2):
-            r, res = q.get(timeout=800)
+            r, res = q.get(timeout=1100)
             got[r] = res
     finally:
         for p in procs:
@@ -119,6 +147,21 @@ def test_two_ranks_on_one_gpu_stay_bit_identical():
                 assert e == sorted(e), (tag, e)
     # BatchNorm statistics are per GPU (the reference has no SyncBN): the ranks saw different data, so they must differ
     assert not np.array_equal(got[0]["irse"][3], got[1]["irse"][3])
+    # the composed C4 step (BASELINE configs[3]): three flat buffers, three reducers, all replicas bit-identical after 3 steps
+    for i, name in enumerate(("fhn", "student", "assistant")):
+        assert np.array_equal(got[0]["c4"][0][i], got[1]["c4"][0][i]), f"c4 {name}: replicas diverged"
+        assert np.isfinite(got[0]["c4"][0][i]).all()
+    for r in (0, 1):
+        _, early3, nbs, losses3 = got[r]["c4"]
+        assert all(np.isfinite(v) for pair in losses3 for v in pair)
+        for i, nb in enumerate(nbs):
+            # every bucket of every buffer was all-reduced in every step, each exactly once
+            assert all(sorted(e[i][0]) == list(range(nb)) for e in early3), (r, i, early3)
+            assert early3[0][i][1] == 0                      # step 1 learns the signal counts
+            # afterwards (nearly) all go out during backward (the FHN buffer holds parameters this step never uses -- the prior's
+            # heads, residual_next: a bucket made of those alone is launched by finish())
+            assert all(e[i][1] >= (nb - 1 if i else nb // 2) for e in early3[1:]), (r, i, early3)
+    assert got[0]["c4"][3] != got[1]["c4"][3]               # different data per rank: local losses differ
 
 
 @pytest.mark.timeout(600)
@@ -133,7 +176,7 @@ def test_bench_two_rank_rehearsal_prints_one_line():
     env = dict(os.environ, XR_REHEARSE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch", "16"]
+           "--batch", "16", "--c4-batch", "4", "--c3-batch", "4"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=540, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -141,7 +184,15 @@ def test_bench_two_rank_rehearsal_prints_one_line():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
-    assert "cpu_baseline" not in line and "secondary" not in line      # rank-0-at-N=1 legs only
+    assert "cpu_baseline" not in line                                   # rank-0-at-N=1 leg only
+    # the multi-GPU configurations (BASELINE configs[3], [2]) are timed in their data-parallel form, all-reduce inside the step
+    sec = {e["workload"][:2]: e for e in line["secondary"]}
+    assert set(sec) == {"C4", "C3"}, line["secondary"]
+    for k, nb in (("C4", 4), ("C3", 4)):
+        assert "error" not in sec[k], sec[k]
+        assert sec[k]["n_gpus"] == 2 and sec[k]["per_gpu_batch"] == nb and sec[k]["ms_per_step"] > 0
+        assert "data parallel" in sec[k]["workload"] and "cpu_baseline" not in sec[k]
+        assert abs(sec[k]["images_per_s"] - 2 * nb / (sec[k]["ms_per_step"] * 1e-3)) <= 0.02 * sec[k]["images_per_s"]
 
 
 @pytest.mark.timeout(300)
