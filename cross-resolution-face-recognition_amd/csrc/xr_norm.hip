@@ -115,8 +115,13 @@ __device__ __forceinline__ void block_reduce_atomic(float (&acc)[NV][8], float* 
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, Geo geo) {
+// PIV: the sums are taken over (x - pivot) with pivot[g][c] = x[g][row 0][c] -- the same value in every block of the group, so the
+// partial sums stay additive -- and the pivot is stored for xr_norm_finalize_pivot, which rebuilds mean = pivot + S1 / n and
+// var = S2 / n - (S1 / n)^2.  E[x^2] - mean^2 on raw fp32 sums loses (mean / std)^2 * 6e-8 of the variance (all of it once
+// |mean| reaches a few thousand std); shifted by a sample of the data itself the two terms are O(var) and nothing cancels.
+template <typename T, bool PIV>
+__global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, float* __restrict__ pivot,
+                                                         Geo geo) {
   extern __shared__ float lds[];
   const int t = threadIdx.x;
   const bool active = t < geo.active;
@@ -130,6 +135,17 @@ __global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x
   for (int e = 0; e < 8; ++e) acc[0][e] = acc[1][e] = 0.f;
   if (active) {
     const T* base = x + ((size_t)g * geo.rows) * geo.C + cch * 8;
+    float pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+    if constexpr (PIV) {
+      ld8(base, pv);
+      if (blockIdx.x == 0 && rsub == 0) {
+        float* pd = pivot + (size_t)g * geo.C + cch * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pd[e] = pv[e];
+      }
+    }
     int r = r_begin + rsub;
     for (; r + 3 * geo.rpb < r_end; r += 4 * geo.rpb) {  // 4 independent 16-B loads in flight per lane
       float v0[8], v1[8], v2[8], v3[8];
@@ -139,6 +155,7 @@ __global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x
       ld8(base + (size_t)(r + 3 * geo.rpb) * geo.C, v3);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+        if constexpr (PIV) { v0[e] -= pv[e]; v1[e] -= pv[e]; v2[e] -= pv[e]; v3[e] -= pv[e]; }
         acc[0][e] += (v0[e] + v1[e]) + (v2[e] + v3[e]);
         acc[1][e] += (v0[e] * v0[e] + v1[e] * v1[e]) + (v2[e] * v2[e] + v3[e] * v3[e]);
       }
@@ -148,6 +165,7 @@ __global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x
       ld8(base + (size_t)r * geo.C, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+        if constexpr (PIV) v[e] -= pv[e];
         acc[0][e] += v[e];
         acc[1][e] += v[e] * v[e];
       }
@@ -159,13 +177,15 @@ __global__ __launch_bounds__(NT) void group_stats_kernel(const T* __restrict__ x
 __global__ void norm_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
                                      const float* __restrict__ beta, float* __restrict__ mean, float* __restrict__ invstd,
                                      float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ rmean,
-                                     float* __restrict__ rvar, int G, int rows, int C, float eps, float momentum) {
+                                     float* __restrict__ rvar, int G, int rows, int C, float eps, float momentum,
+                                     const float* __restrict__ pivot) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= G * C) return;
   const int c = i % C;
   const float n = (float)rows;
-  const float mu = sums[i] / n;
-  float var = sums[(size_t)G * C + i] / n - mu * mu;
+  const float m1 = sums[i] / n;                       // mean of (x - pivot)
+  const float mu = (pivot ? pivot[i] : 0.f) + m1;
+  float var = sums[(size_t)G * C + i] / n - m1 * m1;
   var = var > 0.f ? var : 0.f;
   const float is = rsqrtf(var + eps);
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -187,17 +207,32 @@ __global__ __launch_bounds__(256) void norm_finalize_fold_kernel(const float* __
                                                                  float* __restrict__ invstd, float* __restrict__ scale,
                                                                  float* __restrict__ shift, float* __restrict__ rmean,
                                                                  float* __restrict__ rvar, int fold, int rows, int C, float eps,
-                                                                 float momentum) {
+                                                                 float momentum, const float* __restrict__ pivot) {
   // 256 threads = 8 channels x 32 partial lanes: the fold is a latency chain, so it is kept short (fold / 32 loads per lane)
   __shared__ float part[2][32][8];
   const int cl = threadIdx.x & 7, fl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
   float s0 = 0.f, s1 = 0.f;
+  float p0 = 0.f;
   if (c < C) {
+    if (pivot != nullptr) {
+      // every partial f was taken relative to its OWN pivot p_f (a sample of its rows; equal row counts): re-base to p_0 --
+      // sum (x - p0) = S1_f + n_f d, sum (x - p0)^2 = S2_f + 2 d S1_f + n_f d^2 with d = p_f - p0 of the order of one std
+      p0 = pivot[c];
+      const float nf = (float)rows / (float)fold;
 #pragma unroll 4
-    for (int f = fl; f < fold; f += 32) {   // (unrolled: per-image partials, fold = N, keep eight loads in flight)
-      s0 += sums[(size_t)f * C + c];
-      s1 += sums[((size_t)fold + f) * C + c];
+      for (int f = fl; f < fold; f += 32) {
+        const float a = sums[(size_t)f * C + c], b = sums[((size_t)fold + f) * C + c];
+        const float d = pivot[(size_t)f * C + c] - p0;
+        s0 += a + nf * d;
+        s1 += b + d * (2.f * a + nf * d);
+      }
+    } else {
+#pragma unroll 4
+      for (int f = fl; f < fold; f += 32) {   // (unrolled: per-image partials, fold = N, keep eight loads in flight)
+        s0 += sums[(size_t)f * C + c];
+        s1 += sums[((size_t)fold + f) * C + c];
+      }
     }
   }
   part[0][fl][cl] = s0;
@@ -210,8 +245,9 @@ __global__ __launch_bounds__(256) void norm_finalize_fold_kernel(const float* __
     s1 += part[1][k][cl];
   }
   const float n = (float)rows;
-  const float mu = s0 / n;
-  float var = s1 / n - mu * mu;
+  const float m1 = s0 / n;
+  const float mu = p0 + m1;
+  float var = s1 / n - m1 * m1;
   var = var > 0.f ? var : 0.f;
   const float is = rsqrtf(var + eps);
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
@@ -244,6 +280,7 @@ struct AffP {
   // fused second reduction of the backward apply (xr_affine_act_bwd_apply_red): red2[0][g][c] += sum dx, red2[1][g][c] +=
   // sum dx * y2 over the rows of group g; with bcast the coefficients are per channel and shared by all groups
   const void* y2; float* red2; int bcast;
+  float* pivot;        // xr_affine_act_stats_pivot: [G][C], the statistics are taken relative to it (and it is written)
 };
 
 template <typename T> __device__ __forceinline__ float as_stored(float v);   // the value a later pass reads back
@@ -276,6 +313,27 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(AffP p, Geo geo) {
     const T* x = reinterpret_cast<const T*>(p.x) + gbase;
     const T* res = p.res ? reinterpret_cast<const T*>(p.res) + gbase : nullptr;
     T* y = reinterpret_cast<T*>(p.y) + gbase;
+    float pv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+    if constexpr (STATS) {
+      if (p.pivot != nullptr) {    // pivot = the group's own output at row 0 (every block recomputes the same value)
+        float v[8], rv[8];
+        ld8(x, v);
+        if (res) ld8(res, rv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = v[e] * sc[e] + sh[e];
+          if (res) z += rv[e];
+          pv[e] = as_stored<T>(act_fwd(z, al[e], p.act));
+        }
+        if (blockIdx.x == 0 && rsub == 0) {
+          float* pd = p.pivot + (size_t)g * geo.C + cch * 8;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pd[e] = pv[e];
+        }
+      }
+    }
     for (int r = r_begin + rsub; r < r_end; r += geo.rpb) {
       float v[8], rv[8], o[8];
       ld8(x + (size_t)r * geo.C, v);
@@ -286,7 +344,7 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(AffP p, Geo geo) {
         if (res) z += rv[e];
         o[e] = act_fwd(z, al[e], p.act);
         if constexpr (STATS) {
-          const float q = as_stored<T>(o[e]);
+          const float q = as_stored<T>(o[e]) - pv[e];
           acc[0][e] += q;
           acc[1][e] += q * q;
         }
@@ -804,29 +862,50 @@ static int check_geo(const char* name, int dtype, int G, int rows, int C) {
 
 }  // namespace
 
-extern "C" int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C, void* stream) {
+static int group_stats_run(int dtype, const void* x, float* sums, float* pivot, int G, int rows, int C, void* stream) {
   if (int e = check_geo("xr_group_stats", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && sums, "xr_group_stats: null pointer");
   Geo geo = make_geo(G, rows, C, g_tune[8]);
   const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
-  if (dtype == XR_BF16)
-    hipLaunchKernelGGL(group_stats_kernel<bf16_t>, geo_grid(geo), dim3(NT), smem, (hipStream_t)stream, (const bf16_t*)x, sums, geo);
-  else
-    hipLaunchKernelGGL(group_stats_kernel<float>, geo_grid(geo), dim3(NT), smem, (hipStream_t)stream, (const float*)x, sums, geo);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XR_BF16) {
+    if (pivot) hipLaunchKernelGGL((group_stats_kernel<bf16_t, true>), geo_grid(geo), dim3(NT), smem, st, (const bf16_t*)x, sums, pivot, geo);
+    else hipLaunchKernelGGL((group_stats_kernel<bf16_t, false>), geo_grid(geo), dim3(NT), smem, st, (const bf16_t*)x, sums, pivot, geo);
+  } else {
+    if (pivot) hipLaunchKernelGGL((group_stats_kernel<float, true>), geo_grid(geo), dim3(NT), smem, st, (const float*)x, sums, pivot, geo);
+    else hipLaunchKernelGGL((group_stats_kernel<float, false>), geo_grid(geo), dim3(NT), smem, st, (const float*)x, sums, pivot, geo);
+  }
   XR_CHECK_LAUNCH("xr_group_stats");
   return XR_OK;
+}
+
+extern "C" int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C, void* stream) {
+  return group_stats_run(dtype, x, sums, nullptr, G, rows, C, stream);
+}
+
+extern "C" int xr_group_stats_pivot(int dtype, const void* x, float* sums, float* pivot, int G, int rows, int C, void* stream) {
+  XR_CHECK_ARG(pivot, "xr_group_stats_pivot: null pivot");
+  return group_stats_run(dtype, x, sums, pivot, G, rows, C, stream);
 }
 
 extern "C" int xr_norm_finalize(const float* sums, const float* gamma, const float* beta, float* mean, float* invstd,
                                 float* scale, float* shift, float* running_mean, float* running_var, int G, int rows, int C,
                                 float eps, float momentum, int fold, void* stream) {
+  return xr_norm_finalize_pivot(sums, nullptr, gamma, beta, mean, invstd, scale, shift, running_mean, running_var, G, rows, C, eps,
+                                momentum, fold, stream);
+}
+
+extern "C" int xr_norm_finalize_pivot(const float* sums, const float* pivot, const float* gamma, const float* beta, float* mean,
+                                      float* invstd, float* scale, float* shift, float* running_mean, float* running_var, int G,
+                                      int rows, int C, float eps, float momentum, int fold, void* stream) {
   XR_CHECK_ARG(sums && scale && shift, "xr_norm_finalize: null pointer");
+  XR_CHECK_ARG(pivot == nullptr || fold <= 1 || rows % fold == 0, "xr_norm_finalize_pivot: pivoted partials must cover equal row counts");
   XR_CHECK_ARG(G > 0 && rows > 0 && C > 0, "xr_norm_finalize: bad geometry");
   XR_CHECK_ARG(fold <= 1 || G == 1, "xr_norm_finalize: partial sums (fold > 1) belong to one statistics group (G == 1)");
   if (fold > 1) {
     XR_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "xr_norm_finalize: running stats must come in pairs");
     hipLaunchKernelGGL(norm_finalize_fold_kernel, dim3(cdiv(C, 8)), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, mean,
-                       invstd, scale, shift, running_mean, running_var, fold, rows, C, eps, momentum);
+                       invstd, scale, shift, running_mean, running_var, fold, rows, C, eps, momentum, pivot);
     XR_CHECK_LAUNCH("xr_norm_finalize");
     return XR_OK;
   }
@@ -834,7 +913,7 @@ extern "C" int xr_norm_finalize(const float* sums, const float* gamma, const flo
   XR_CHECK_ARG(running_mean == nullptr || G == 1, "xr_norm_finalize: running statistics need G == 1");
   const int n = G * C;
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, mean,
-                     invstd, scale, shift, running_mean, running_var, G, rows, C, eps, momentum);
+                     invstd, scale, shift, running_mean, running_var, G, rows, C, eps, momentum, pivot);
   XR_CHECK_LAUNCH("xr_norm_finalize");
   return XR_OK;
 }
@@ -862,10 +941,17 @@ extern "C" int xr_affine_act(int dtype, const void* x, const float* scale, const
 extern "C" int xr_affine_act_stats(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                                    const float* alpha, int act, void* y, float* stats, int G, int rows, int C,
                                    int coef_per_group, void* stream) {
+  return xr_affine_act_stats_pivot(dtype, x, scale, shift, res, alpha, act, y, stats, nullptr, G, rows, C, coef_per_group, stream);
+}
+
+extern "C" int xr_affine_act_stats_pivot(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                         const float* alpha, int act, void* y, float* stats, float* pivot, int G, int rows, int C,
+                                         int coef_per_group, void* stream) {
   if (int e = check_geo("xr_affine_act_stats", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && y && stats, "xr_affine_act_stats: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_stats: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, y, nullptr, stats, nullptr, nullptr, nullptr, coef_per_group, nullptr};
+  p.pivot = pivot;
   Geo geo = make_geo(G, rows, C, g_tune[8]);
   const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
   if (dtype == XR_BF16)

@@ -13,8 +13,10 @@ forward, backward, optimizer update, BatchNorm counter bumps, weight re-packs --
   frozen: re-capture after changing them.  Steps taken by replays are not reflected in the optimizer's host-side counter.
 
 Replays change parameters and BatchNorm running statistics behind the host's back (no tensor version bump), so every
-replay invalidates the host-side caches keyed on them (weight packs, eval-mode BatchNorm coefficients): an eager
-evaluation between replays sees the current weights.
+replay invalidates the host-side caches keyed on them (weight packs, eval-mode BatchNorm coefficients) -- for exactly the
+parameters / layers the warm-up saw the step update: an eager evaluation between replays sees the current weights, and a
+frozen network's packs are never rebuilt.  Mixing eager optimizer steps with replays of the same optimizer is not supported
+(the replay's skip mask and step counter are those of the capture).
 
 Teardown is explicit: ``close()`` (also run by ``__del__``) first waits for the device -- a replay may still be in flight
 when the last reference dies, and destroying an executing graph or releasing its private memory pool under running
@@ -41,9 +43,15 @@ class GraphedStep:
         side = torch.cuda.Stream(dev)
         self._streams = [cur, side]
         side.wait_stream(cur)
+        self._touched = {"params": {}, "bns": {}}
         with torch.cuda.stream(side):   # warm-up: lazy initialisation, weight-pack tables, allocator pools
-            for _ in range(warmup):
-                fn(*self.static_in)
+            for i in range(warmup):
+                # the last warm-up step also records what the step moves behind the host's back (see __call__)
+                ops._touch_log[0] = self._touched if i == warmup - 1 else None
+                try:
+                    fn(*self.static_in)
+                finally:
+                    ops._touch_log[0] = None
             # the set of stale weight packs the captured step will meet (this step's own parameters; other models' pending
             # refreshes were flushed by the warm-up) gets its descriptor table now -- a capture cannot build one
             ops._pack_plan.prebuild()
@@ -84,7 +92,19 @@ class GraphedStep:
             if s.data_ptr() != t.data_ptr():
                 s.copy_(t, non_blocking=True)
         self.graph.replay()
-        ops.invalidate_weight_cache()   # the replay moved parameters / running statistics without bumping any version
+        # the replay moved parameters / running statistics without bumping any version: invalidate the host-side caches keyed on
+        # them -- exactly the parameters the step's fused optimizers update and the BatchNorm layers it runs in training mode
+        # (recorded in the warm-up); the packs / eval coefficients of everything else (a frozen teacher) stay valid.  A step that
+        # recorded no fused update (stock optimizers write through tensor ops the capture froze) invalidates everything.
+        params = [r() for r in self._touched["params"].values()]
+        if params:
+            ops.invalidate_weight_cache([p for p in params if p is not None])
+            for r in self._touched["bns"].values():
+                m = r()
+                if m is not None:
+                    m.__dict__["_xr_stat_epoch"] = m.__dict__.get("_xr_stat_epoch", 0) + 1
+        else:
+            ops.invalidate_weight_cache()
         return self.static_out
 
     def close(self):

@@ -110,6 +110,10 @@ class _BNMixin:
             # the training forward rewrites running_mean / running_var through raw pointers (xr_norm_finalize): no tensor
             # version changes, so the cached eval-mode coefficients are keyed on this counter as well
             self.__dict__["_xr_stat_epoch"] = self.__dict__.get("_xr_stat_epoch", 0) + 1
+            log = ops._touch_log[0]
+            if log is not None:
+                import weakref
+                log["bns"][id(self)] = weakref.ref(self)
             if self.num_batches_tracked is not None and not _NBT_BATCHED[0]:
                 self.num_batches_tracked.add_(1)
 

@@ -307,14 +307,22 @@ def _probe_begin(tag, on=None):
 _pack_epoch = [0]
 
 
+# GraphedStep's warm-up records which parameters the step's fused optimizers update and which BatchNorm layers run in training
+# mode (their running statistics move): a replay then invalidates exactly those caches instead of everything
+_touch_log = [None]      # None | {"params": {id: weakref}, "bns": {id: weakref}}
+
+
 def invalidate_weight_cache(params=None):
     """Fused optimizers update parameters through raw pointers (no version bump): they call this, with the parameters
     they touched (packs of other, e.g. frozen-teacher, parameters stay valid) or without (everything is stale)."""
     if params is None:
         _pack_epoch[0] += 1
     else:
+        log = _touch_log[0]
         for p in params:
             p.__dict__["_xr_epoch"] = p.__dict__.get("_xr_epoch", 0) + 1
+            if log is not None:
+                log["params"][id(p)] = weakref.ref(p)
 
 
 def _pack_tag(w):
@@ -879,16 +887,18 @@ class StatsLink:
     def __init__(self):
         self.sums = None
         self.key = None
+        self.pivot = None     # [fold][C]: the partial sums are relative to it (xr_affine_act_stats_pivot), or None
 
-    def deliver(self, y, sums):
-        self.sums, self.key = sums, (y.data_ptr(), y._version, tuple(y.shape))
+    def deliver(self, y, sums, pivot=None):
+        self.sums, self.pivot, self.key = sums, pivot, (y.data_ptr(), y._version, tuple(y.shape))
 
     def take(self, x):
-        sums, key = self.sums, self.key
-        self.sums = self.key = None
+        """(sums, pivot) delivered for exactly this tensor, or None."""
+        sums, pivot, key = self.sums, self.pivot, self.key
+        self.sums = self.key = self.pivot = None
         if sums is None or key != (x.data_ptr(), x._version, tuple(x.shape)):
             return None
-        return sums
+        return sums, pivot
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, stats_link=None):
@@ -945,30 +955,31 @@ class _NormAct(Function):
             pg = max(d for d in range(1, min(N, 32) + 1) if N % d == 0)
             per_img = pg > 1
         pre = slink.take(x) if (slink is not None and stats and mode == "bn") else None
-        if pre is not None:   # the producing convolution already summed x and x^2 per channel (StatsLink)
+        if pre is not None:   # the producer already summed x and x^2 per channel (StatsLink): a convolution epilogue, or the
+            pre, piv = pre    # elementwise pass that wrote x (then relative to a pivot per partial)
             mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             upd = rmean is not None
-            lib.xr_norm_finalize(ptr(pre), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                 ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
-                                 pre.shape[1], stream())
+            lib.xr_norm_finalize_pivot(ptr(pre), ptr(piv), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                       ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
+                                       pre.shape[1], stream())
         elif stats:
-            if per_img:
-                sums_n = zeros_f32((2, pg, C), dev)
-                lib.xr_group_stats(dt(x), ptr(x), ptr(sums_n), pg, (N // pg) * H * W, C, stream())
-                sums = sums_n     # folded inside xr_norm_finalize
-                if not _cfg["fold_finalize"]:
-                    sums = torch.empty((2, 1, C), **f32)
-                    lib.xr_reduce_groups(ptr(sums_n), ptr(sums), 2, pg, C, 0, stream())
+            # statistics relative to a pivot (the group's first element): E[x^2] - mean^2 on raw fp32 sums cancels for
+            # |mean| >> std (aten::batch_norm / instance_norm use a shifted / Welford form, model_irse.py:56-60)
+            if per_img and _cfg["fold_finalize"]:
+                sums = zeros_f32((2, pg, C), dev)      # folded inside xr_norm_finalize_pivot
+                piv = torch.empty((pg, C), **f32)
+                lib.xr_group_stats_pivot(dt(x), ptr(x), ptr(sums), ptr(piv), pg, (N // pg) * H * W, C, stream())
             else:
                 sums = zeros_f32((2, G, C), dev)
-                lib.xr_group_stats(dt(x), ptr(x), ptr(sums), G, rows, C, stream())
+                piv = torch.empty((G, C), **f32)
+                lib.xr_group_stats_pivot(dt(x), ptr(x), ptr(sums), ptr(piv), G, rows, C, stream())
             mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
             upd = mode == "bn" and rmean is not None
-            lib.xr_norm_finalize(ptr(sums), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                 ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
-                                 pg if (per_img and _cfg["fold_finalize"]) else 1, stream())
+            lib.xr_norm_finalize_pivot(ptr(sums), ptr(piv), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                       ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
+                                       pg if (per_img and _cfg["fold_finalize"]) else 1, stream())
         elif mode == "bn":
             if eval_coef is not None:   # frozen network: (scale, shift) cached by the layer (nn._BNMixin)
                 scale, shift = eval_coef
@@ -980,10 +991,11 @@ class _NormAct(Function):
         if offer is not None and mode == "bn" and N > 1:
             # the output opens a residual unit whose BatchNorm wants its statistics: one group per image, shared coefficients
             osum = zeros_f32((2, N, C), dev)
-            lib.xr_affine_act_stats(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), ptr(osum), N, H * W, C, 0,
-                                    stream())
+            opiv = torch.empty((N, C), **f32)
+            lib.xr_affine_act_stats_pivot(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), ptr(osum), ptr(opiv), N,
+                                          H * W, C, 0, stream())
             offer.slink = StatsLink()
-            offer.slink.deliver(y, osum)
+            offer.slink.deliver(y, osum, opiv)
         else:
             lib.xr_affine_act(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(y), G, rows, C, 1, stream())
         ctx.save_for_backward(x, res, scale, shift, mean, invstd, gm, al, rmean, rvar)
@@ -1605,10 +1617,11 @@ class _BnSeAdd(Function):
         if tail is not None:   # the statistics of `out` ride along for the BatchNorm that opens the next unit
             tail.y = y
             osum = zeros_f32((2, N, C), dev)
-            lib.xr_affine_act_stats(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), ptr(osum), N, HW, C, 1,
-                                    stream())
+            opiv = torch.empty((N, C), **f32)
+            lib.xr_affine_act_stats_pivot(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), ptr(osum), ptr(opiv), N, HW,
+                                          C, 1, stream())
             tail.slink = StatsLink()
-            tail.slink.deliver(out, osum)
+            tail.slink.deliver(out, osum, opiv)
         else:
             lib.xr_affine_act(dt(y), ptr(y), ptr(cA), ptr(cB), ptr(sc), None, ACT_NONE, ptr(out), N, HW, C, 1, stream())
         ctx.save_for_backward(y, sums_n, a, b, mean, invstd, gm, w1f, w2f, pooled, hidden, s)

@@ -39,27 +39,32 @@ class FlatParams:
             p.__dict__["_xr_touched"] = False
             # gradients that arrive through autograd's AccumulateGrad (stock torch ops, direct=False) count as touched too
             p.register_post_accumulate_grad_hook(_mark_touched)
-        self._mask_key = None
-        self._mask = None
+        self._masks = {}
 
     def touched_mask(self, no_decay_ids=()):
         """uint8 per element for the fused optimizers (xr_*_step ``wd_mask``): bit 0 = weight decay applies, bit 1 = the
         parameter received no gradient since the last zero_grad() -> left untouched (a stock optimizer skips .grad None).
-        Returns None when every parameter was touched and none is decay-free.  Cached per touched-set."""
-        key = tuple(p.__dict__.get("_xr_touched", False) for p in self.params)
-        if key != self._mask_key:
-            self._mask_key = key
-            if all(key) and not no_decay_ids:
-                self._mask = None
+        Returns None when every parameter was touched and none is decay-free.  One device mask per (touched set, decay-free
+        set), kept for the lifetime of this object: a captured HIP graph holds the raw pointer of the mask it was captured
+        with, so a mask is never freed or rewritten once handed out (a training loop sees two or three distinct sets)."""
+        key = (tuple(p.__dict__.get("_xr_touched", False) for p in self.params), frozenset(no_decay_ids))
+        if key not in self._masks:
+            if all(key[0]) and not no_decay_ids:
+                self._masks[key] = None
             else:
                 m = torch.ones(self.numel, dtype=torch.uint8)
-                for p, o, t in zip(self.params, self.offsets, key):
+                for p, o, t in zip(self.params, self.offsets, key[0]):
                     if not t:
                         m[o:o + p.numel()] = 2
                     elif id(p) in no_decay_ids:
                         m[o:o + p.numel()] = 0
-                self._mask = m.to(self.flat.device)
-        return self._mask
+                if self.flat.is_cuda:   # pinned staging: the upload is an asynchronous copy (legal inside a graph capture)
+                    m = m.pin_memory()
+                dm = torch.empty(self.numel, dtype=torch.uint8, device=self.flat.device)
+                dm.copy_(m, non_blocking=True)
+                self._masks[key] = dm
+                self._mask_hosts = getattr(self, "_mask_hosts", []) + [m]   # keep the pinned source alive until the copy ran
+        return self._masks[key]
 
     def zero_grad(self):
         """One memset; .grad tensors stay allocated views (autograd accumulates in place)."""
@@ -218,17 +223,23 @@ class _FlatOptimizer(torch.optim.Optimizer):
         """torch.optim.Optimizer.state_dict() plus the flat state buffers and the step count (momentum / second moments /
         bias-correction step live outside ``self.state`` -- one buffer each, not one entry per parameter)."""
         sd = super().state_dict()
-        sd["xr_flat"] = {"steps": self._steps, "numel": self.flat.numel,
+        sd["xr_flat"] = {"steps": self._steps, "numel": self.flat.numel, "shapes": [tuple(p.shape) for p in self.flat.params],
                          **{k: getattr(self, k).detach().clone() for k in self._STATE}}
         return sd
 
     def load_state_dict(self, state_dict):
+        """Everything is validated BEFORE anything is mutated (torch's own load rewrites param_groups first)."""
         state_dict = dict(state_dict)
         fl = state_dict.pop("xr_flat", None)
-        super().load_state_dict(state_dict)
         if fl is None:
             raise RuntimeError("not a fused flat optimizer checkpoint (no 'xr_flat' entry): momentum would silently reset")
-        assert fl["numel"] == self.flat.numel, "checkpoint was written for a different parameter layout"
+        if int(fl["numel"]) != self.flat.numel or ("shapes" in fl and [tuple(s) for s in fl["shapes"]] != [tuple(p.shape) for p in self.flat.params]):
+            raise RuntimeError("fused flat optimizer checkpoint was written for a different parameter layout "
+                               f"({fl['numel']} elements vs {self.flat.numel})")
+        for k in self._STATE:
+            if k not in fl or fl[k].numel() != self.flat.numel:
+                raise RuntimeError(f"fused flat optimizer checkpoint: state buffer '{k}' missing or of the wrong size")
+        super().load_state_dict(state_dict)
         self._steps = int(fl["steps"])
         for k in self._STATE:
             getattr(self, k).copy_(fl[k])
@@ -273,7 +284,11 @@ class FusedRMSprop(_FlatOptimizer):
 
 
 class FusedAdam(_FlatOptimizer):
-    """torch.optim.Adam(betas, eps, weight_decay) (SUPER_RESOLUTION/train_FHN.py:115-121)."""
+    """torch.optim.Adam(betas, eps, weight_decay) (SUPER_RESOLUTION/train_FHN.py:115-121).
+    Deviation (documented, parity unpinned by any fixture): the bias corrections use ONE step count for the whole buffer;
+    torch.optim.Adam keeps a per-parameter count that only advances when .grad is not None, so a parameter FIRST touched at
+    step k > 1 gets slightly different corrections here (parameters touched from step 1 on -- every parameter of the
+    reference's steps -- are identical)."""
     _STATE = ("m", "v")
 
     def __init__(self, flat, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):

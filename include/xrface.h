@@ -190,6 +190,10 @@ int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, i
 
 /* sums[0][g][c] += sum x, sums[1][g][c] += sum x^2 (fp32; caller zeroes `sums`, 2*G*C floats). */
 int xr_group_stats(int dtype, const void* x, float* sums, int G, int rows, int C, void* stream);
+/* The same sums taken over (x - pivot[g][c]) with pivot[g][c] = x[g][0][c] (written by the kernel, [G][C] fp32): the form every
+ * normalisation statistic takes (aten::batch_norm / instance_norm compute a shifted / Welford variance; E[x^2] - mean^2 on raw fp32
+ * sums cancels for |mean| >> std).  Consumed by xr_norm_finalize_pivot. */
+int xr_group_stats_pivot(int dtype, const void* x, float* sums, float* pivot, int G, int rows, int C, void* stream);
 
 /* From sums: mean/invstd (biased variance, eps), scale = gamma*invstd, shift = beta - mean*scale
  * (gamma/beta NULL -> 1/0).  If running_mean/var != NULL (BatchNorm training): running =
@@ -199,6 +203,11 @@ int xr_norm_finalize(const float* sums, const float* gamma, const float* beta, f
                      float eps, float momentum, int fold, void* stream);
 /* fold > 1 (G must be 1): `sums` is [2][fold][C], partial sums of the one statistics group (per-image or pseudo-group
  * partials of a BatchNorm); they are added up inside the same launch.  fold <= 1: `sums` is [2][G][C]. */
+/* pivot != NULL: sums were taken relative to pivot ([G][C], or [fold][C] for partials of one group -- each partial relative to
+ * its own pivot and over rows / fold rows): mean = pivot + S1 / n, var = S2 / n - (S1 / n)^2.  pivot == NULL: xr_norm_finalize. */
+int xr_norm_finalize_pivot(const float* sums, const float* pivot, const float* gamma, const float* beta, float* mean, float* invstd,
+                           float* scale, float* shift, float* running_mean, float* running_var, int G, int rows, int C, float eps,
+                           float momentum, int fold, void* stream);
 
 /* Eval-mode BatchNorm: scale/shift [C] from running statistics. */
 int xr_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -218,6 +227,10 @@ int xr_affine_act(int dtype, const void* x, const float* scale, const float* shi
 int xr_affine_act_stats(int dtype, const void* x, const float* scale, const float* shift, const void* res,
                         const float* alpha, int act, void* y, float* stats, int G, int rows, int C, int coef_per_group,
                         void* stream);
+/* ... with the statistics taken relative to pivot[g][c] = y[g][0][c] (written; [G][C]): see xr_group_stats_pivot. */
+int xr_affine_act_stats_pivot(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                              const float* alpha, int act, void* y, float* stats, float* pivot, int G, int rows, int C,
+                              int coef_per_group, void* stream);
 
 /* Backward, pass 1:  z = x*scale+shift+res ; dz = dy*act'(z)
  *   red[0][g][c] += sum dz ; red[1][g][c] += sum dz*x ; red[2][g][c] += sum dy*z*[z<=0]  (PReLU dalpha)

@@ -317,6 +317,62 @@ def test_norm_act(mode, act, with_res, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["bn", "in", "bn_chained"])
+def test_norm_statistics_of_an_offset_input(mode, dtype):
+    """Batch / instance statistics of an input with |mean| >> std (mean ~ 1e3, std ~ 1 in fp32; bf16 inputs are quantised to the
+    bf16 grid first, spacing 4-8 at 1e3, both sides see the same values) against aten::batch_norm / instance_norm in fp32
+    (model_irse.py:56-60 BatchNorm semantics, model/FSRnet.py:81 InstanceNorm): E[x^2] - mean^2 on raw fp32 sums loses the
+    variance entirely here (the clamp then gives invstd = 1 / sqrt(eps)); the pivoted sums must not.  ``bn_chained``: the
+    statistics come out of the elementwise pass that produced the tensor (xr_affine_act_stats_pivot, TailLink / offer_stats)."""
+    from xrface import ops
+    N, C, H, W = 6, 64, 12, 10
+    off = (rnd("off", C) * 300.0 + 1000.0).reshape(1, C, 1, 1)
+    x = rnd("offx" + mode, N, C, H, W) * (1.0 if dtype == torch.float32 else 16.0) + off
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    gamma, beta = rnd("og", C) * 0.3 + 1.0, rnd("ob", C) * 0.2
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    if mode == "in":
+        y_ref = F.instance_norm(xr, None, None, gamma, beta, True, 0.0, 1e-5)
+    else:
+        y_ref = F.batch_norm(xr, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    gy = rnd("ogy", N, C, H, W)
+    y_ref.backward(gy)
+    xg = x.clone().to(DEV).requires_grad_(True)
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    gg, bg = gamma.to(DEV), beta.to(DEV)
+    if mode == "bn_chained":
+        # producer: an identity elementwise pass (scale 1, shift 0) that offers the statistics of its output to the BatchNorm
+        ident = ops.enter(xg, dtype).detach()
+        osum = ops.zeros_f32((2, N, C), ident.device)
+        opiv = torch.empty((N, C), dtype=torch.float32, device=DEV)
+        buf = torch.empty_like(ident)
+        from xrface._lib import ACT_NONE, dt, lib, ptr, stream
+        lib.xr_affine_act_stats_pivot(dt(ident), ptr(ident.detach()), None, None, None, None, ACT_NONE, ptr(buf), ptr(osum), ptr(opiv), N,
+                                      H * W, C, 0, stream())
+        sl = ops.StatsLink()
+        sl.deliver(buf, osum, opiv)
+        yb = ops.norm_act(buf, gg, bg, rmg, rvg, mode="bn", training=True, slink=sl)
+        assert sl.sums is None       # taken
+    else:
+        yb = ops.norm_act(ops.enter(xg, dtype), gg, bg, rmg if mode == "bn" else None, rvg if mode == "bn" else None,
+                          mode="in" if mode == "in" else "bn", training=True)
+    y = ops.leave(yb)
+    # outputs are O(1): absolute error against the fp32 reference (bf16 mode: the OUTPUT is rounded to bf16, 2^-8 relative)
+    tol = 2e-3 if dtype == torch.float32 else 3e-2
+    err = float((y.detach().float().cpu() - y_ref.detach()).abs().max())
+    assert err < tol, err
+    if mode != "in":
+        assert rel(rmg, rm_ref) < 1e-5 and rel(rvg, rv_ref) < (2e-3 if dtype == torch.float32 else 1e-4), (rel(rmg, rm_ref), rel(rvg, rv_ref))
+    if mode != "bn_chained":
+        y.backward(gy.to(DEV).to(y.dtype))
+        gerr = float((xg.grad.float().cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+        assert gerr < (2e-2 if dtype == torch.float32 else 6e-2), gerr
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_se_scale_add(dtype):
     from xrface import ops
     N, C, H = 3, 64, 9
