@@ -53,6 +53,10 @@ __device__ __forceinline__ int lds_off_t(int row, int chunk) {
   else return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
 }
 
+// MODE: 0 bf16 tensors (one plane); 1 fp32 tensors split into three bf16 planes, six plane-pair MFMAs per product (all 24
+// significand bits); 2 fp32 tensors split into two planes, three MFMAs (hi*hi, hi*lo, lo*hi: ~16 significand bits -- XR_F32X2)
+__host__ __device__ constexpr int ns_of(int mode) { return mode == 1 ? 3 : (mode == 2 ? 2 : 1); }
+
 // fp32 -> NP bf16 planes with x ~= sum_p plane[p] (3 planes carry all 24 significand bits)
 template <int NP>
 __device__ __forceinline__ void split8(const float (&v)[8], uint4 (&pl)[NP]) {
@@ -101,12 +105,12 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
   static_assert(BKT == 64 || (BKT == 32 && DMA != 0), "32-element stages exist for the DMA path only");
   constexpr int WN = 4 / WM;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int NS = MODE ? 3 : 1;
+  constexpr int NS = ns_of(MODE);
   constexpr int CPW = BKT / 8;        // 16-B chunks per stage row
   constexpr int RPP = NT / CPW;       // tile rows covered by one pass of the 256 threads
   constexpr int RA = BM / RPP, RB = BN / RPP;
   constexpr int ROWB = BKT * 2;       // stage row bytes
-  using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
+  using in_t = typename std::conditional<MODE != 0, float, bf16_t>::type;
   using out_t = in_t;
   constexpr int PADE = 16 / sizeof(out_t);
 
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const unsigned voff = ((a_mlo[i] >> sh) & 1u) ? (unsigned)(a_off[i] + dby) : XR_OOR;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff, 0, 0);
         const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsA, voff + 16u, 0, 0);
 #pragma unroll
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
       int pix = 0;
       bool ok = a_valid[i] && tap_ok && tap_coord<TR>(a_oh[i], a_ow[i], r, s, p.stride, p.H, p.W, pix);
       const in_t* src = in + ((size_t)(a_nb[i] + pix) * p.C + c);
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         if (ok) {
           ld8(src, a_f[i]);
         } else {
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int off = lds_off(rbase + 32 * i, cc);
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         uint4 pl[NS];
         split8<NS>(a_f[i], pl);
 #pragma unroll
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
 
 template <int MODE, int BM, int BN, int DMA, int BKT>
 constexpr size_t igemm_smem() {
-  constexpr int NS = MODE ? 3 : 1;
+  constexpr int NS = ns_of(MODE);
   constexpr size_t ops = (size_t)NS * (BM + BN) * (BKT * 2) * (DMA ? DMA : 1);
   constexpr size_t esz = MODE ? 4 : 2;
   constexpr size_t stg = (size_t)BM * (BN + 16 / esz) * esz;
@@ -599,7 +603,7 @@ template <int MODE, int BM, int BN, int WM, bool TR>
 int launch_igemm(IgemmP& p, hipStream_t st) {
   const bool cls_ok = TR && p.stride > 1 && p.Ho % p.stride == 0 && p.Wo % p.stride == 0 && p.C % 64 == 0 && p.ws == nullptr;
   const long long in_bytes = (long long)p.N * p.H * p.W * p.C * (MODE ? 4 : 2);
-  const long long w_bytes = (long long)(MODE ? 3 : 1) * p.K * p.Kg * 2;
+  const long long w_bytes = (long long)ns_of(MODE) * p.K * p.Kg * 2;
   int ntaps = p.R * p.S;
   if (cls_ok) ntaps = ((p.R + p.stride - 1) / p.stride) * ((p.S + p.stride - 1) / p.stride);
   const bool fast = g_tune[0] && p.C % 64 == 0 && (!TR || p.stride == 1 || cls_ok) && ntaps <= 32 &&
@@ -705,7 +709,7 @@ __device__ __forceinline__ bf16x8_t tr_frag_sw(const unsigned char* img, int pix
 template <int MODE, int BR, int BC, bool TR, int NBUF, bool FAST>
 __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int BP = 64;  // pixels per stage
-  constexpr int NS = MODE ? 3 : 1;
+  constexpr int NS = ns_of(MODE);
   constexpr int WC = BC / 64, WR = BR / 64;  // wave grid (wave tile 64x64)
   static_assert(WC * WR == 4, "4 waves");
   // NBUF == 2 on the bf16 FAST path = LDS-DMA staging: both images go global -> LDS by buffer_load ... lds (no staging
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
   constexpr int PY = DMA ? BR * 2 : BR * 2 + 64, PX = DMA ? BC * 2 : BC * 2 + 64;  // padded pitches: == 64 (mod 256) -> conflict-free tr reads
   constexpr int CRY = BR / 8, CRX = BC / 8;          // chunks per image row
   constexpr int NY = BP * CRY / NT, NX = BP * CRX / NT;
-  using in_t = typename std::conditional<MODE == 1, float, bf16_t>::type;
+  using in_t = typename std::conditional<MODE != 0, float, bf16_t>::type;
 
   constexpr int STAGE = NS * BP * (PY + PX);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -790,7 +794,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
     for (int i = 0; i < NY; ++i) {
       const int m = mbase + yrow0 + (NT / CRY) * i;
       const unsigned voff = m < p.M ? y_base[i] : XR_OOR;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsY, voff, ysoff, 0);
         const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsY, voff + 16u, ysoff, 0);
 #pragma unroll
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       const bool ok = col_ok && mbase + xrow0 + (NT / CRX) * i < p.M && (unsigned)xhv[i] < (unsigned)p.H &&
                       (unsigned)xwv[i] < (unsigned)p.W;
       const unsigned voff = ok ? (unsigned)xl[i] : XR_OOR;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         const v4u_t u0 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff, 0, 0);
         const v4u_t u1 = __builtin_amdgcn_raw_buffer_load_b128(rsX, voff + 16u, 0, 0);
 #pragma unroll
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       const int m = mbase + yrow0 + (NT / CRY) * i;
       const bool ok = ycol_ok && m < p.M;
       const in_t* src = dy + ((size_t)m * p.ldy + r0 + ych * 8);
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         if (ok) ld8(src, y_f[i]);
         else {
 #pragma unroll
@@ -882,7 +886,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
       decode_pixel<TR>(m, p.M, p.fd_howo, p.fd_wo, HW, p.stride, p.pad, valid, nb, oh0, ow0);
       const bool ok = valid && col_ok && tap_coord<TR>(oh0, ow0, tr_, ts_, p.stride, p.H, p.W, pix);
       const in_t* src = in + ((size_t)(nb + pix) * p.C + cch);
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         if (ok) ld8(src, x_f[i]);
         else {
 #pragma unroll
@@ -899,7 +903,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
       const int off = (yrow0 + (NT / CRY) * i) * PY + ych * 16;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         uint4 pl[NS];
         split8<NS>(y_f[i], pl);
 #pragma unroll
@@ -911,7 +915,7 @@ __global__ __launch_bounds__(NT) void wgrad_kernel(WgradP p) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int off = (xrow0 + (NT / CRX) * i) * PX + xch * 16;
-      if constexpr (MODE == 1) {
+      if constexpr (MODE != 0) {
         uint4 pl[NS];
         split8<NS>(x_f[i], pl);
 #pragma unroll
@@ -1046,7 +1050,7 @@ int launch_wgrad(WgradP& p, int split, hipStream_t st) {
 
 template <int MODE, int BR, int BC, bool TR, int NBUF, bool FAST>
 int launch_wgrad_nb(WgradP& p, int split, hipStream_t st) {
-  constexpr int NS = MODE ? 3 : 1;
+  constexpr int NS = ns_of(MODE);
   constexpr bool DMA = NBUF == 2 && FAST && MODE == 0;
   constexpr size_t smem = DMA ? (size_t)2 * 64 * (BR * 2 + BC * 2) : (size_t)NS * 64 * ((BR * 2 + 64) + (BC * 2 + 64)) * NBUF;
   p.fd_howo = make_fd((unsigned)(p.Ho * p.Wo));
@@ -1378,7 +1382,7 @@ extern "C" int xr_pack_plan(const int64_t* entries, int n, void* table_dev, int*
     e.dst = reinterpret_cast<bf16_t*>((uintptr_t)f[1]);
     e.nplanes = (int)f[2]; e.A1 = (int)f[3]; e.A2 = (int)f[4]; e.taps = (int)f[5]; e.B = (int)f[6]; e.Bp = (int)f[7]; e.Kg = (int)f[8];
     e.sa1 = f[9]; e.sa2 = f[10]; e.st = f[11]; e.sb = f[12];
-    XR_CHECK_ARG(e.src && e.dst && (e.nplanes == 1 || e.nplanes == 3) && e.A1 > 0 && e.A2 > 0 && e.taps > 0 && e.B > 0 &&
+    XR_CHECK_ARG(e.src && e.dst && (e.nplanes >= 1 && e.nplanes <= 3) && e.A1 > 0 && e.A2 > 0 && e.taps > 0 && e.B > 0 &&
                      e.Bp >= e.B && e.Bp % 8 == 0 && e.Kg % 64 == 0 && e.Kg >= e.taps * e.Bp,
                  "xr_pack_plan: bad entry %d", i);
     e.total = (int64_t)e.A1 * e.A2 * e.Kg;
@@ -1438,7 +1442,7 @@ extern "C" int xr_bias_cast(int dtype, const float* ws, const float* bias, void*
 
 extern "C" int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int taps, int B, int Bp,
                               int Kg, int64_t sa1, int64_t sa2, int64_t st_, int64_t sb, void* stream) {
-  XR_CHECK_ARG(src && dst && (nplanes == 1 || nplanes == 3), "xr_pack_weight: null pointer or nplanes not in {1,3}");
+  XR_CHECK_ARG(src && dst && nplanes >= 1 && nplanes <= 3, "xr_pack_weight: null pointer or nplanes not in {1,2,3}");
   XR_CHECK_ARG(A1 > 0 && A2 > 0 && taps > 0 && B > 0 && Bp >= B && Bp % 8 == 0 && Kg % 64 == 0 && Kg >= taps * Bp,
                "xr_pack_weight: bad dims A1=%d A2=%d taps=%d B=%d Bp=%d Kg=%d", A1, A2, taps, B, Bp, Kg);
   hipStream_t st_h = (hipStream_t)stream;
@@ -1543,7 +1547,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
                              int N, int H, int W, int C, int Ho, int Wo, int K, int R, int S, int stride, int pad,
                              int transposed, int Kg, int ldo, float* splitk_ws, int splitk, const void* ep_src,
                              const float* ep_alpha, float* ep_dalpha, int ep_spread, void* ep2_out, float* ep_red, const void* ep_add, void* stream) {
-  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_igemm: bad dtype %d", dtype);
+  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32 || dtype == XR_F32X2, "xr_conv_igemm: bad dtype %d", dtype);
   XR_CHECK_ARG(ep_src == nullptr || ep_red != nullptr ||
                    (ep_alpha && ep_dalpha && K % 8 == 0 && splitk_ws == nullptr && bias == nullptr),
                "xr_conv_igemm: fused PReLU-backward epilogue needs alpha, dalpha, K %% 8 == 0, no bias, no split-K");
@@ -1584,6 +1588,10 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
       return transposed ? launch_igemm<0, 128, 32, 4, true>(p, st) : launch_igemm<0, 128, 32, 4, false>(p, st);
     return transposed ? launch_igemm<0, 128, 64, 4, true>(p, st) : launch_igemm<0, 128, 64, 4, false>(p, st);
   }
+  if (dtype == XR_F32X2) {
+    if (wide) return transposed ? launch_igemm<2, 128, 128, 2, true>(p, st) : launch_igemm<2, 128, 128, 2, false>(p, st);
+    return transposed ? launch_igemm<2, 128, 64, 4, true>(p, st) : launch_igemm<2, 128, 64, 4, false>(p, st);
+  }
   if (wide) return transposed ? launch_igemm<1, 128, 128, 2, true>(p, st) : launch_igemm<1, 128, 128, 2, false>(p, st);
   return transposed ? launch_igemm<1, 128, 64, 4, true>(p, st) : launch_igemm<1, 128, 64, 4, false>(p, st);
 }
@@ -1591,7 +1599,7 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
 extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,
                              int Wo, int K, int R, int S, int stride, int pad, int transposed, int ldy, int Kg, int split,
                              void* stream) {
-  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_conv_wgrad: bad dtype %d", dtype);
+  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32 || dtype == XR_F32X2, "xr_conv_wgrad: bad dtype %d", dtype);
   XR_CHECK_ARG(in && dy && dwp, "xr_conv_wgrad: null pointer");
   XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0,
                "xr_conv_wgrad: non-positive dimension");
@@ -1608,6 +1616,10 @@ extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* d
   if (dtype == XR_BF16) {
     if (tall) return transposed ? launch_wgrad<0, 128, 128, true>(p, split, st) : launch_wgrad<0, 128, 128, false>(p, split, st);
     return transposed ? launch_wgrad<0, 64, 256, true>(p, split, st) : launch_wgrad<0, 64, 256, false>(p, split, st);
+  }
+  if (dtype == XR_F32X2) {
+    if (tall) return transposed ? launch_wgrad<2, 128, 128, true>(p, split, st) : launch_wgrad<2, 128, 128, false>(p, split, st);
+    return transposed ? launch_wgrad<2, 64, 256, true>(p, split, st) : launch_wgrad<2, 64, 256, false>(p, split, st);
   }
   if (tall) return transposed ? launch_wgrad<1, 128, 128, true>(p, split, st) : launch_wgrad<1, 128, 128, false>(p, split, st);
   return transposed ? launch_wgrad<1, 64, 256, true>(p, split, st) : launch_wgrad<1, 64, 256, false>(p, split, st);

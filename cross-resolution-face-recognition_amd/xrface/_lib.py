@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XR_LIB") or os.path.join(_HERE, "libxrface.so")   # XR_LIB: A/B a differently built library
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "xrface.h"))
 
-XR_BF16, XR_F32 = 0, 1
+XR_BF16, XR_F32, XR_F32X2 = 0, 1, 2
 ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3
 
 _CT = {

@@ -13,7 +13,7 @@ import weakref
 import torch
 from torch.autograd import Function
 
-from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, dt, lib, ptr, stream
+from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, XR_F32X2, dt, lib, ptr, stream
 
 EPS = 1e-5
 import os as _os
@@ -21,14 +21,29 @@ _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_
         "lockstep": int(_os.environ.get("XR_LOCKSTEP", "1")), "wgrad_rows": int(_os.environ.get("XR_WGRAD_ROWS", "2")),
         "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
         "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")), "direct64_prelu": 1,
-        "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0"))}
+        "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0")), "f32_planes": 3,
+        "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1"))}
 
 
 def set_compute_dtype(dtype):
-    """Activation dtype chosen at module entry for fp32 NCHW inputs: torch.float32 (parity mode: split-bf16
-    MFMA, ~fp32 accuracy) or torch.bfloat16 (throughput mode)."""
+    """Activation dtype chosen at module entry for fp32 NCHW inputs: torch.float32 (parity mode: fp32 tensors, every matrix
+    operand split into three bf16 planes, six MFMAs per product, ~fp32 accuracy), "fp32x2" (fp32 tensors, TWO planes, three
+    MFMAs per product: ~16 significand bits, inside the 1e-3 embedding tolerance at half the matrix work) or torch.bfloat16
+    (throughput mode)."""
+    if dtype == "fp32x2":
+        _cfg["compute_dtype"], _cfg["f32_planes"] = torch.float32, 2
+        return
     assert dtype in (torch.float32, torch.bfloat16)
     _cfg["compute_dtype"] = dtype
+    if dtype == torch.float32:
+        _cfg["f32_planes"] = 3
+
+
+def dtc(t):
+    """dtype code for the matrix kernels (xr_conv_igemm / xr_conv_wgrad): fp32 tensors run with 3 or 2 bf16 planes."""
+    if t.dtype == torch.float32 and _cfg["f32_planes"] == 2:
+        return XR_F32X2
+    return dt(t)
 
 
 def get_compute_dtype():
@@ -240,7 +255,7 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
         elif rows:
             ns = lib.xr_conv_wgrad_rows(ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, K, stride, split, sh)
         else:
-            ns = lib.xr_conv_wgrad(dt(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
+            ns = lib.xr_conv_wgrad(dtc(x), ptr(x), ptr(dy), ptr(slabs), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp,
                                    kg, split, sh)
         if pe is not None:
             if on is None:
@@ -251,7 +266,11 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
 
     # (not while a HIP graph is being captured: graphs stay single-stream -- a captured fork/join brought nothing at the
     # small batch sizes graphs are for, and multi-stream graph teardown is the less-trodden path of the runtime)
-    if tgt is not None and _cfg["wgrad_stream"] and not _graph["capturing"]:
+    # (wgrad64_stream: the direct 64-channel weight-gradient kernel keeps one persistent 147 KB-LDS workgroup per CU; beside the
+    # direct forward / input-gradient kernels of the main stream (120 KB) the two only take turns on the CUs, so in the FHN step
+    # alone the side stream buys nothing for it (C3 N = 128: 36.41 vs 36.42 ms in the interleaved A/B) -- in the composed step it
+    # still overlaps the IR-SE-50 chains: C4 105.2 vs 106.7 ms, so it stays on)
+    if tgt is not None and _cfg["wgrad_stream"] and not _graph["capturing"] and (not d64 or _cfg["wgrad64_stream"]):
         dev = x.device
         side = _side_fork(dev)     # side stream now waits for everything enqueued on the current stream (x, dy, zeroed grads)
         sh = side.cuda_stream      # launch on the side stream by handle: no current-stream switch on the host
@@ -422,7 +441,8 @@ def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
     """Pack an fp32 parameter for the implicit-GEMM kernels.  The pack is cached ON the parameter object
     (so it dies with it) and is refreshed whenever the parameter's version / storage / epoch changes."""
     cache = w.__dict__.setdefault("_xr_pack", {})
-    key = (kind, dtype, Bp)
+    planes = _cfg["f32_planes"] if dtype == torch.float32 else 1
+    key = (kind, dtype, Bp, planes)
     tag = _pack_tag(w)
     hit = cache.get(key)
     if hit is not None and hit[0] == tag:
@@ -434,7 +454,6 @@ def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
             return hit[1], hit[2]
     kg = kg_of(taps, Bp)
     rows = A1 * A2
-    planes = 3 if dtype == torch.float32 else 1
     pk = torch.empty((planes, rows, kg), dtype=torch.bfloat16, device=w.device)
     wd = w.detach()
     plain = wd.dtype == torch.float32 and wd.is_contiguous()
@@ -601,7 +620,7 @@ class _Conv2d(Function):
             # implicit-GEMM / bwdred paths below: ctx.direct64 stays False)
             lib.xr_conv64_direct_prelu(ptr(x), ptr(pk), ptr(y), ptr(p2), ptr(al), N, H, W, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
+            lib.xr_conv_igemm(dtc(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0,
                               kg, Kp, None, 0, None, ptr(al), None, ssp, ptr(p2), ptr(sred), None, stream())
         if sred is not None:
             stats_link.deliver(y, sred)
@@ -668,7 +687,7 @@ class _Conv2d(Function):
                 lib.xr_conv64_direct_bwdred(ptr(dy), ptr(pk), ptr(dx), N, H, W, 1, ptr(link.x), ptr(one), ptr(zero), None, ptr(red),
                                             stream())
             else:
-                lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
+                lib.xr_conv_igemm(dtc(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1,
                                   kg, Cp, None, 0, ptr(link.x) if red is not None else None, None, None, sp_, None, ptr(red),
                                   ptr(dpass) if add_in_kernel else None, stream())
             if pe is not None:
@@ -704,7 +723,7 @@ class _ConvTranspose2d(Function):
         Kp = r8(Cout)
         y = torch.empty((N, Ho, Wo, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
-        lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
+        lib.xr_conv_igemm(dtc(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, Cp, Ho, Wo, Cout, R, S, stride, pad, 1,
                           kg, Kp, None, 0, None, None, None, 1, None, None, None, stream())
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, b is not None)
@@ -726,7 +745,7 @@ class _ConvTranspose2d(Function):
             # dx[n,hi,wi,ci] = sum dy[n, hi*s - p + r, ., co] w[ci][co][r][s]: an ordinary strided conv over dy
             pk, kg = _packed(w, "tdgrad", x.dtype, Cin, 1, R * S, Cout, Kp, Cout * R * S, 0, 1, R * S)
             dx = torch.empty_like(x)
-            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
+            lib.xr_conv_igemm(dtc(x), ptr(dy), ptr(pk), None, ptr(dx), N, Ho, Wo, Kp, H, W, Cin, R, S, stride, pad, 0,
                               kg, Cp, None, 0, None, None, None, 1, None, None, None, stream())
         if ctx.needs_input_grad[1] and _wanted(w):
             # dw[ci][co][r][s] = sum_{n,hi,wi} x[n,hi,wi,ci] * dy[n, hi*s - p + r, wi*s - p + s', co]: the weight gradient of an
@@ -759,11 +778,11 @@ class _LinearNHWC(Function):
         split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None, None, None,
+            lib.xr_conv_igemm(dtc(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None, None, None,
                               stream())
             lib.xr_bias_cast(dt(y), ptr(ws), ptr(bf), ptr(y), N, K, Kp, stream())
         else:
-            lib.xr_conv_igemm(dt(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None, None, None,
+            lib.xr_conv_igemm(dtc(x), ptr(x), ptr(pk), ptr(bf), ptr(y), N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, None, 0, None, None, None, 1, None, None, None,
                               stream())
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
@@ -784,7 +803,7 @@ class _LinearNHWC(Function):
             # plain GEMM dx[n][p*C + c] = sum_k dy[n][k] w[k][c*HW + p]: a 1x1 "conv" with HW*C output channels
             pk, kg = _packed(w, "lin_dgrad", x.dtype, HW, C, 1, K, Kp, 1, HW, 0, C * HW)
             dx = torch.empty_like(x)
-            lib.xr_conv_igemm(dt(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
+            lib.xr_conv_igemm(dtc(x), ptr(dy), ptr(pk), None, ptr(dx), N, 1, 1, Kp, 1, 1, HW * C, 1, 1, 1, 0, 0, kg,
                               HW * C, None, 0, None, None, None, 1, None, None, None, stream())
         if ctx.needs_input_grad[1] and _wanted(w):
             kg = kg_of(HW, C)
@@ -816,7 +835,7 @@ class _PreluConv2d(Function):
             _conv64(p1, pk, y2, tag=("fwd", Cp, K, H, W, R, stride))      # 64 -> 64 stride 1: the direct kernel
         else:
             pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
-            lib.xr_conv_igemm(dt(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
+            lib.xr_conv_igemm(dtc(y1), ptr(p1), ptr(pk), None, ptr(y2), N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, 0, kg, Kp, None, 0,
                               None, None, None, 1, None, None, None, stream())
             if pe is not None:
                 pe.record()
@@ -851,7 +870,7 @@ class _PreluConv2d(Function):
             pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
             pe = _probe_begin(("dgrad", Cp, K, H, W, R, stride))
-            lib.xr_conv_igemm(dt(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
+            lib.xr_conv_igemm(dtc(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
                               0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, None, stream())
             if pe is not None:
                 pe.record()

@@ -38,6 +38,9 @@ extern "C" {
 
 #define XR_BF16 0
 #define XR_F32 1
+#define XR_F32X2 2  /* xr_conv_igemm / xr_conv_wgrad only: fp32 tensors, operands split into TWO bf16 planes (hi + lo), three
+                     * plane-pair MFMAs per product (hi*hi, hi*lo, lo*hi; ~16 significand bits) -- half the matrix work of XR_F32;
+                     * every other entry point sees such tensors as XR_F32 */
 
 #define XR_ACT_NONE 0
 #define XR_ACT_PRELU 1  /* per-channel slope */
@@ -57,7 +60,7 @@ int xr_tune(int knob, int value);
  * Linear [K][C*H*W], model_irse.py:147).  Before a step the host packs them for the implicit-GEMM
  * kernels:   dst[a][t*Bp + b] = src[a1*sa1 + a2*sa2 + t*st + b*sb],  a = a1*A2 + a2,
  * rows padded with zeros to Kg (multiple of 64), b padded to Bp (multiple of 8).
- * nplanes = 1 (XR_BF16) or 3 (XR_F32: w = p0 + p1 + p2, each bf16, together all 24 significand bits);
+ * nplanes = 1 (XR_BF16), 3 (XR_F32: w = p0 + p1 + p2, each bf16, together all 24 significand bits) or 2 (XR_F32X2: p0 + p1);
  * dst holds the planes back to back: [nplanes][A1*A2][Kg] bf16. */
 int xr_pack_weight(const float* src, void* dst, int nplanes, int A1, int A2, int taps, int B, int Bp, int Kg,
                    int64_t sa1, int64_t sa2, int64_t st, int64_t sb, void* stream);

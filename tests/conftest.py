@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _three_plane_fp32_by_default():
+    """The fp32 matrix mode is process-wide state (ops.set_compute_dtype("fp32x2") selects two planes): a test that switched to two
+    planes must not leak it into op tests that enter fp32 tensors directly."""
+    yield
+    ops = sys.modules.get("xrface.ops")
+    if ops is not None:
+        ops._cfg["f32_planes"] = 3
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

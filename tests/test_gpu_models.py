@@ -182,6 +182,42 @@ def test_ir_backbone_eval_and_train(tag, se):
     assert step_err < 5e-3, step_err
 
 
+def test_irse50_two_plane_fp32_mode_meets_the_embedding_tolerance():
+    """north_star: "embeddings within 1e-3 of the CPU reference".  bf16 tensors miss it (7e-3, asserted < 1.1e-2 below); the
+    three-plane fp32 mode holds it at ~1e-6 but costs six MFMAs per product.  XR_F32X2 (two planes, three MFMAs) must hold it too:
+    eval-mode embedding relative L2 error < 1e-3 against the reference fixture, train-mode output / loss within 1e-3, gradients
+    within the same bound as the three-plane mode."""
+    import xrface
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model import model_irse
+    from xrface.steps import teacher_step
+    xrface.set_compute_dtype("fp32x2")
+    st = load_gold("irse.npz")
+    net, sd = load_det(model_irse.IR_SE_50([112, 112]))
+    x = G.synth_faces(8, 112, seed=1, start=100)
+    tgt = G.synth_labels(8, 512, seed=2)
+    net.eval()
+    with torch.no_grad():
+        emb = net(x[:2].to(DEV))
+    ref = torch.from_numpy(st["irse50/eval/emb"])
+    e_rel = float((emb.float().cpu() - ref).norm(dim=1).max() / ref.norm(dim=1).min())
+    print(f"fp32x2 embedding rel L2 error {e_rel:.3e}")
+    assert e_rel < TOL, f"two-plane fp32 mode: embedding L2 error {e_rel:.2e}"
+    check_against(st, "irse50/eval/emb", emb, TOL, what="fp32x2 irse50/eval/emb")
+    net.train()
+    net.output_layer[1].p = 0.0
+    loss, out = teacher_step(net, x.to(DEV), tgt.to(DEV), criterion=CrossEntropyLoss())
+    check_against(st, "irse50/train/emb", out, TOL, what="fp32x2 irse50/train/emb")
+    assert abs(loss.item() - float(st["irse50/train/loss"])) <= TOL * abs(float(st["irse50/train/loss"]))
+    g = grads_by_name(net)
+    floor = grad_floor(st, "irse50/train/grad/")
+    for key in st.files:
+        pre = "irse50/train/grad/"
+        if key.startswith(pre):
+            name = key[len(pre):].replace("@digest", "")
+            check_against(st, pre + name, g[name], GRAD_TOL, floor=floor, what="fp32x2 " + pre + name)
+
+
 def test_ir_dropout_mask_matches_oracle():
     import xrface
     from xrface.model import model_irse

@@ -81,6 +81,32 @@ def test_conv2d_fwd_bwd(case, dtype):
         assert rel(bg.grad, br.grad) < tol
 
 
+@pytest.mark.parametrize("case", [CONV_CASES[0], CONV_CASES[3], CONV_CASES[5], CONV_CASES[8], CONV_CASES[10]])
+def test_conv2d_two_plane_fp32_mode(case):
+    """XR_F32X2 (ops.set_compute_dtype("fp32x2")): fp32 tensors, operands split into hi + lo bf16 planes, three plane-pair MFMAs per
+    product.  Forward, input gradient and weight gradient against the fp32 CPU convolution: ~16 significand bits per operand
+    -> a few 1e-5 relative to max-abs (bar 1e-4; the three-plane mode sits at ~1e-6, bf16 at ~1e-2), and measurably MORE than
+    the three-plane mode on the same operands (i.e. the two-plane kernels really ran)."""
+    from xrface import ops
+    N, C, H, W, K, R, stride, pad, bias = case
+    x = rnd(f"cx{case}", N, C, H, W)
+    w = rnd(f"cw{case}", K, C, R, R, scale=(C * R * R) ** -0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, stride, pad)
+    gy = rnd(f"cg{case}", *y_ref.shape)
+    y_ref.backward(gy)
+    errs = {}
+    for mode in ("fp32x2", torch.float32):
+        ops.set_compute_dtype(mode)
+        xg, wg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        y = ops.leave(ops.conv2d(ops.enter(xg, torch.float32), wg, None, stride, pad), K)
+        y.backward(gy.to(DEV))
+        errs[mode] = (rel(y, y_ref), rel(xg.grad, xr.grad), rel(wg.grad, wr.grad))
+    assert max(errs["fp32x2"]) < 1e-4, errs
+    assert max(errs[torch.float32]) < 2e-5, errs
+    assert min(errs["fp32x2"]) > 1.5 * max(errs[torch.float32]) or max(errs["fp32x2"]) < 2e-6, errs
+
+
 CONV8_CASES = [
     # N, C, H, W, K, R, stride, pad, bias  -- the 8-wave 256x256 kernel forced on (xr_tune knob 7 = 2)
     (2, 64, 14, 14, 256, 3, 1, 1, False),    # 392 rows: one full + one ragged row tile

@@ -62,6 +62,24 @@ if os.environ.get("WORKLOAD") == "c4":  # the composed north-star step (BASELINE
         steps.c4_step(fhn, student, assistant, teacher, lr4, hr4, optimizers=opts4)
 
 
+if os.environ.get("WORKLOAD") == "c3":  # the full FHN step (BASELINE configs[2] per-GPU shape)
+    from xrface import steps
+    from xrface.model import FSRnet
+    n = int(os.environ.get("N", 128))
+    fhn = {"coarse": FSRnet.Course_SR_Network().to(dev), "prior": FSRnet.Prior_Estimation_Network().to(dev),
+           "encoder": FSRnet.Fine_SR_Encoder().to(dev), "decoder": FSRnet.Fine_SR_Decoder().to(dev)}
+    flats3 = {k: parallel.FlatParams(fhn[k].parameters()) for k in fhn}
+    opts3 = {k: parallel.FusedRMSprop(flats3[k], lr=1e-5, weight_decay=1e-5) for k in fhn}
+    hr3 = bench.synth_batch(n, dev, 12)[0]
+    lr3 = bench.synth_lr(hr3)
+    hm3 = torch.rand(n, 28, 28, device=dev)
+    par3 = torch.randint(0, 11, (n, 1, 28, 28), device=dev)
+    del model, flat, opt
+
+    def step():
+        steps.fhn_step_fused(fhn, lr3, hr3, hm3, par3, optimizers=opts3)
+
+
 # VARIANTS="name:knob=val,knob=val;..." ; special key: wb = ops wgrad_blocks
 variants = []
 for spec in os.environ.get("VARIANTS", "base:;wprio:5=1").split(";"):
