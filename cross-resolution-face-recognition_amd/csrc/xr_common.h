@@ -17,7 +17,8 @@ struct XrTune {
   operator int() const { return v.load(std::memory_order_relaxed); }
   XrTune& operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
 };
-extern XrTune g_tune[16];
+extern XrTune g_tune[20];
+#define XR_DET() (g_tune[16] != 0)   // deterministic reductions (xr_set_deterministic): no order-dependent fp32 atomics
 
 typedef unsigned short bf16_t;  // raw bf16 storage
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

@@ -593,7 +593,7 @@ constexpr size_t igemm_smem() {
 }
 
 }  // namespace
-XrTune g_tune[16] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 1, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [13] 8-wave ring weight gradient (xr_wgrad8.hip): 0 off, 1 auto (K >= 256), 2 whenever eligible; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
+XrTune g_tune[20] = {3, 1, 0, 0, 1, 1, 18, 1, 1024, 1024, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0};  // [0] igemm gather path: 0 generic, 1 FAST (register staging), 2 FAST + LDS-DMA, 3 auto; [2] != 0 disables wgrad FAST; [3] != 0: 128x64 tiles for every K; [4], [5] unused (s_setprio around the MFMA groups is unconditional); [6] DMA threshold (K stages); [7] 8-wave 256x256 kernel (xr_conv8.hip): 0 off, 1 auto, 2 whenever eligible; [8]/[9] reduce-kernel block targets (xr_norm.hip); [12] 8-wave kernel prefetch schedule: 1 = deep (5-6 phases ahead, default), 0 = shallow; [13] 8-wave ring weight gradient (xr_wgrad8.hip): 0 off, 1 auto (K >= 256), 2 whenever eligible; [11] wgrad LDS-DMA staging (0 off: faster on warm inputs in tools/conv_bench.py, slower inside the training step, where operands come from HBM), 1 auto, 2 always
 namespace {
 
 template <int MODE, int BM, int BN, int WM, bool TR, bool FAST, int DMA, int BKT = 64>
@@ -1423,8 +1423,13 @@ extern "C" int xr_pack_run(const void* table_dev, int n, int blocks, int smem, v
 }
 
 extern "C" int xr_tune(int knob, int value) {
-  XR_CHECK_ARG(knob >= 0 && knob < 16, "xr_tune: knob out of range");
+  XR_CHECK_ARG(knob >= 0 && knob < 20, "xr_tune: knob out of range");
   g_tune[knob] = value;
+  return XR_OK;
+}
+
+extern "C" int xr_set_deterministic(int on) {
+  g_tune[16] = on ? 1 : 0;
   return XR_OK;
 }
 
@@ -1492,6 +1497,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
     int groups = 1;
     if (tiles < 1024 && nslices > 8) groups = cdiv(nslices, g_tune[10] > 0 ? (int)g_tune[10] : (tiles < 128 ? 8 : 16));   // few output tiles, many slices (knob 10: slices per group)
     if (groups > 64) groups = 64;
+    if (XR_DET()) groups = 1;   // the slice groups meet in dst by atomics: one group sums the slices in order
     const int spg = cdiv(nslices, groups);
     groups = cdiv(nslices, spg);
     if (groups > 1 && !(accumulate & 1)) {
@@ -1512,6 +1518,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
     // few outputs but many slices (the 64-channel layers): spread the slices over blockIdx.y and meet by atomics
     int groups = 1;
     if (blocks < 512 && nslices > 16) groups = (nslices + 15) / 16;
+    if (XR_DET()) groups = 1;
     const int spg = (nslices + groups - 1) / groups;
     groups = (nslices + spg - 1) / spg;
     if (groups > 1 && !(accumulate & 1)) {
@@ -1529,6 +1536,7 @@ extern "C" int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, 
   if (blocks > 8192) blocks = 8192;
   int groups = 1;
   if (blocks < 512 && nslices > 16) groups = (nslices + 15) / 16;
+  if (XR_DET()) groups = 1;
   const int spg = (nslices + groups - 1) / groups;
   groups = (nslices + spg - 1) / spg;
   if (groups > 1 && !(accumulate & 1)) {

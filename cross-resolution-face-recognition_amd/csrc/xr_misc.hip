@@ -19,6 +19,9 @@ static inline int grid_for(int64_t n, int per_block = NT, int cap = 8192) {
   return (int)b;
 }
 
+// deterministic mode: the loss scalar is the sum of ONE block (the blocks otherwise meet in it by fp32 atomics)
+static inline int det_grid(int g) { return XR_DET() ? 1 : g; }
+
 #define GRID_STRIDE(i, n) \
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
@@ -858,7 +861,7 @@ extern "C" int xr_loss_mse(int dtype, const void* a, const void* b, float scale,
   XR_CHECK_ARG(a && b && (loss || da || db) && n > 0 && n_valid > 0, "xr_loss_mse: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const float ls = scale / (float)n_valid, gc = gscale * 2.f * scale / (float)n_valid;
-  XR_DISPATCH(dtype, hipLaunchKernelGGL(loss_mse_kernel<T>, dim3(grid_for(n, NT * 4, 2048)), dim3(NT), 0, st, (const T*)a,
+  XR_DISPATCH(dtype, hipLaunchKernelGGL(loss_mse_kernel<T>, dim3(loss ? det_grid(grid_for(n, NT * 4, 2048)) : grid_for(n, NT * 4, 2048)), dim3(NT), 0, st, (const T*)a,
                                         (const T*)b, ls, gc, loss, (T*)da, (T*)db, n, gscale_dev));
   XR_CHECK_LAUNCH("xr_loss_mse");
   return XR_OK;
@@ -868,7 +871,7 @@ extern "C" int xr_loss_landmark(const float* pred, const float* target, float sc
   XR_CHECK_ARG(pred && target && (loss || dpred) && N > 0 && C > 0 && HW > 0, "xr_loss_landmark: bad arguments");
   const int64_t NP = (int64_t)N * HW;
   const float ls = scale / (float)NP, gc = gscale * 2.f * scale / (float)NP;
-  hipLaunchKernelGGL(loss_landmark_nchw_kernel, dim3(grid_for(NP, NT, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target, ls,
+  hipLaunchKernelGGL(loss_landmark_nchw_kernel, dim3(loss ? det_grid(grid_for(NP, NT, 2048)) : grid_for(NP, NT, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target, ls,
                      gc, loss, dpred, NP, C, HW, gscale_dev);
   XR_CHECK_LAUNCH("xr_loss_landmark");
   return XR_OK;
@@ -877,7 +880,7 @@ extern "C" int xr_loss_ce_nchw(const float* pred, const int64_t* target, float g
                                int HW, const float* gscale_dev, void* stream) {
   XR_CHECK_ARG(pred && target && (loss || dpred) && N > 0 && C > 0 && HW > 0, "xr_loss_ce_nchw: bad arguments");
   const int64_t NP = (int64_t)N * HW;
-  hipLaunchKernelGGL(loss_ce_nchw_kernel, dim3(grid_for(NP, NT, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target,
+  hipLaunchKernelGGL(loss_ce_nchw_kernel, dim3(loss ? det_grid(grid_for(NP, NT, 2048)) : grid_for(NP, NT, 2048)), dim3(NT), 0, (hipStream_t)stream, pred, target,
                      gscale / (float)NP, 1.f / (float)NP, loss, dpred, NP, C, HW, gscale_dev);
   XR_CHECK_LAUNCH("xr_loss_ce_nchw");
   return XR_OK;
@@ -887,7 +890,7 @@ extern "C" int xr_loss_softmax_ce(int dtype, const void* pred, const int64_t* ta
   XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32, "xr_loss_softmax_ce: bad dtype");
   XR_CHECK_ARG(pred && target && (loss || dpred) && M > 0 && C > 0 && ld >= C, "xr_loss_softmax_ce: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  XR_DISPATCH(dtype, hipLaunchKernelGGL(loss_softmax_ce_kernel<T>, dim3(grid_for(M, 4, 2048)), dim3(NT), 0, st, (const T*)pred,
+  XR_DISPATCH(dtype, hipLaunchKernelGGL(loss_softmax_ce_kernel<T>, dim3(loss ? det_grid(grid_for(M, 4, 2048)) : grid_for(M, 4, 2048)), dim3(NT), 0, st, (const T*)pred,
                                         target, gscale / (float)M, 1.f / (float)M, loss, (T*)dpred, M, C, ld, gscale_dev));
   XR_CHECK_LAUNCH("xr_loss_softmax_ce");
   return XR_OK;

@@ -18,7 +18,7 @@ struct Geo {
   int G, rows, C, cpr, rpb, active, rows_per_block;
 };
 
-static Geo make_geo(int G, int rows, int C, int target_blocks) {
+static Geo make_geo(int G, int rows, int C, int target_blocks, bool reduces = false) {
   Geo g;
   g.G = G; g.rows = rows; g.C = C;
   g.cpr = C / 8;
@@ -26,6 +26,10 @@ static Geo make_geo(int G, int rows, int C, int target_blocks) {
   g.active = g.rpb * g.cpr;
   int nb = target_blocks / (G > 0 ? G : 1);
   if (nb < 1) nb = 1;
+  // deterministic mode: ONE block per group, so every (group, channel) sum is formed by one block in a fixed order (shuffle
+  // ladder, LDS hop) and lands in zeroed memory through a single add -- hosts then ask for one group per image / per tile and
+  // fold the groups in order (xr_norm_finalize_pivot / xr_norm_bwd_coeffs fold, xr_reduce_groups)
+  if (XR_DET() && reduces) nb = 1;
   int rpbk = cdiv(rows, nb);
   rpbk = cdiv(rpbk, g.rpb) * g.rpb;
   if (rpbk < g.rpb) rpbk = g.rpb;
@@ -865,7 +869,7 @@ static int check_geo(const char* name, int dtype, int G, int rows, int C) {
 static int group_stats_run(int dtype, const void* x, float* sums, float* pivot, int G, int rows, int C, void* stream) {
   if (int e = check_geo("xr_group_stats", dtype, G, rows, C)) return e;
   XR_CHECK_ARG(x && sums, "xr_group_stats: null pointer");
-  Geo geo = make_geo(G, rows, C, g_tune[8]);
+  Geo geo = make_geo(G, rows, C, g_tune[8], true);
   const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == XR_BF16) {
@@ -952,7 +956,7 @@ extern "C" int xr_affine_act_stats_pivot(int dtype, const void* x, const float* 
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_stats: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, y, nullptr, stats, nullptr, nullptr, nullptr, coef_per_group, nullptr};
   p.pivot = pivot;
-  Geo geo = make_geo(G, rows, C, g_tune[8]);
+  Geo geo = make_geo(G, rows, C, g_tune[8], true);
   const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_kernel<bf16_t, true>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_stats");
@@ -966,7 +970,7 @@ extern "C" int xr_affine_act_bwd_reduce(int dtype, const void* x, const float* s
   XR_CHECK_ARG(x && dy && red, "xr_affine_act_bwd_reduce: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_reduce: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, nullptr, dy, red, nullptr, nullptr, nullptr, coef_per_group, nullptr};
-  Geo geo = make_geo(G, rows, C, g_tune[9]);
+  Geo geo = make_geo(G, rows, C, g_tune[9], true);
   const size_t smem = (size_t)(geo.rpb > 12 ? geo.rpb : 12) * C * sizeof(float);
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_bwd_reduce_kernel<bf16_t>, p, geo, smem, (hipStream_t)stream, "xr_affine_act_bwd_reduce");
@@ -983,7 +987,7 @@ extern "C" int xr_norm_bwd_coeffs(const float* red, const float* gamma, const fl
     XR_CHECK_LAUNCH("xr_norm_bwd_coeffs");
     return XR_OK;
   }
-  const int gy = G >= 8 ? (G < 64 ? G : 64) : 1;
+  const int gy = (G >= 8 && !XR_DET()) ? (G < 64 ? G : 64) : 1;   // (y blocks meet in dgamma / dbeta / dalpha by atomics)
   hipLaunchKernelGGL(norm_bwd_coeffs_kernel, dim3(cdiv(C, 128), gy), dim3(128), 0, (hipStream_t)stream, red, gamma, mean, invstd,
                      coef, dgamma, dbeta, dalpha, G, rows, C);
   XR_CHECK_LAUNCH("xr_norm_bwd_coeffs");
@@ -1018,7 +1022,7 @@ extern "C" int xr_affine_act_bwd_apply_red(int dtype, const void* x, const float
   XR_CHECK_ARG(x && dy && dx && y2 && red2, "xr_affine_act_bwd_apply_red: null pointer");
   XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_apply_red: PReLU needs alpha");
   AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, dres, 1, dx_add, y2, red2, 1};
-  Geo geo = make_geo(G, rows, C, 2 * g_tune[9]);   // five streams per row: wants twice the blocks of the plain reduce (tools/norm_bench.py)
+  Geo geo = make_geo(G, rows, C, 2 * g_tune[9], true);   // five streams per row: wants twice the blocks of the plain reduce (tools/norm_bench.py)
   const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t, true>, p, geo, smem, (hipStream_t)stream,
@@ -1082,7 +1086,7 @@ extern "C" int xr_small_atb(const float* A, const float* B, float* out, int N, i
       return XR_E_LAUNCH;
     }
   }
-  int slices = N >= 64 ? 16 : 1;
+  int slices = (N >= 64 && !XR_DET()) ? 16 : 1;
   const int nper = cdiv(N, slices);
   slices = cdiv(N, nper);
   hipLaunchKernelGGL(small_atb_kernel, dim3(cdiv((long long)I * J, 256), slices), dim3(256), 0, (hipStream_t)stream, A, B, out,

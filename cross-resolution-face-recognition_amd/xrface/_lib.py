@@ -67,6 +67,8 @@ class _Lib:
             fn.restype = res
             fn.argtypes = args
         self._dll = dll
+        if os.environ.get("XR_DETERMINISTIC", "0") == "1":   # device half of ops.set_deterministic (the host half reads the same variable)
+            dll.xr_set_deterministic(1)
         for kv in filter(None, os.environ.get("XR_TUNE", "").split(",")):  # e.g. XR_TUNE="7=0,6=18": kernel tuning knobs
             k, v = kv.split("=")
             dll.xr_tune(int(k), int(v))

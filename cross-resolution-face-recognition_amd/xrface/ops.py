@@ -22,7 +22,11 @@ _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_
         "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
         "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")), "direct64_prelu": 1,
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0")), "f32_planes": 3,
-        "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1"))}
+        "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1")), "deterministic": 0}
+
+
+if _os.environ.get("XR_DETERMINISTIC", "0") == "1":   # host half of the switch (see set_deterministic); _lib.load() sets the device half
+    _cfg["deterministic"], _cfg["direct64"] = 1, 0
 
 
 def set_compute_dtype(dtype):
@@ -37,6 +41,36 @@ def set_compute_dtype(dtype):
     _cfg["compute_dtype"] = dtype
     if dtype == torch.float32:
         _cfg["f32_planes"] = 3
+
+
+_det_saved = {}
+
+
+def set_deterministic(on=True):
+    """XR_DETERMINISTIC: every fp32 sum of a step is formed in a fixed order, so two runs of the same step on the same data give
+    bit-identical gradients and weights (replica-divergence debugging, exact repeat tests).  Device side (xr_set_deterministic):
+    one reduction block per statistics group, weight-gradient slices summed by one group, loss scalars by one block.  Host
+    side (here): one statistics group per image, one partial row per convolution tile for the epilogue reductions (dalpha /
+    BatchNorm sums; folded in row order by the kernels that consume them), no split-K, and the fused direct 64-channel kernels
+    -- whose per-image sums meet by atomics from several workgroups -- give way to the implicit-GEMM path with standalone
+    statistics passes.  Slower (the switch is a debugging tool); results differ from the default mode only by summation order."""
+    on = bool(on)
+    if on == bool(_cfg.get("deterministic")):
+        return
+    lib.xr_set_deterministic(int(on))
+    if on:
+        _det_saved.update(direct64=_cfg["direct64"])
+        _cfg["direct64"] = 0
+    else:
+        _cfg["direct64"] = _det_saved.pop("direct64", 1)
+    _cfg["deterministic"] = int(on)
+
+
+def _tile_rows(m, default):
+    """Partial rows for a convolution epilogue reduction over m GEMM rows: ``default`` spread rows shared by the tiles (atomics),
+    or -- deterministic mode -- one row per tile: every tile configuration covers >= 128 rows, so ceil(m / 128) rows are never
+    shared (tile i adds into row i % spread)."""
+    return (m + 127) // 128 if _cfg.get("deterministic") else default
 
 
 def dtc(t):
@@ -553,6 +587,12 @@ def leave2d(buf):
 # ------------------------------------------------------------------------------------------------- convolution
 def _bias_grad(dy, K):
     N, Ho, Wo, Kp = dy.shape
+    if _cfg.get("deterministic") and N > 1:    # one block per image, the images summed in a fixed order
+        sums = zeros_f32((2, N, Kp), dy.device)
+        lib.xr_group_stats(dt(dy), ptr(dy), ptr(sums), N, Ho * Wo, Kp, stream())
+        out = torch.empty((Kp,), dtype=torch.float32, device=dy.device)
+        lib.xr_reduce_groups(ptr(sums), ptr(out), 1, N, Kp, 0, stream())
+        return out[:K]
     sums = zeros_f32((2, 1, Kp), dy.device)
     lib.xr_group_stats(dt(dy), ptr(dy), ptr(sums), 1, N * Ho * Wo, Kp, stream())
     return sums[0, 0, :K]
@@ -612,7 +652,7 @@ class _Conv2d(Function):
         # stats_link: the BatchNorm that follows wants sum / sum of squares of y per channel: taken in the epilogue
         sred, ssp = None, 1
         if stats_link is not None and p2 is None and K % 8 == 0 and _cfg["fuse_conv_stats"]:
-            ssp = StatsLink.SPREAD
+            ssp = _tile_rows(N * Ho * Wo, StatsLink.SPREAD)
             sred = zeros_f32((3, ssp, Kp), x.device)
         pe = _probe_begin(("fwd", Cp, K, H, W, R, stride))
         if p2 is not None and bf is None and sred is None and _cfg["direct64_prelu"] and direct64_ok(x, w, stride, pad):
@@ -669,7 +709,7 @@ class _Conv2d(Function):
             link, red, sp_ = ctx.bn_link, None, 1
             if link is not None and link.x is not None and _cfg["fuse_bn_reduce"] and C % 8 == 0 and link.x.shape == x.shape \
                     and link.x.dtype == x.dtype:
-                sp_ = BnLink.SPREAD
+                sp_ = _tile_rows(N * H * W, BnLink.SPREAD)
                 red = zeros_f32((3, sp_, C), x.device)
             dpass = _dp2 if ctx.passthrough else None
             if dpass is not None:
@@ -775,7 +815,7 @@ class _LinearNHWC(Function):
         y = torch.empty((N, 1, 1, Kp), dtype=x.dtype, device=x.device)
         bf = None if b is None else _c(b.detach().float())
         tiles = ((N + 127) // 128) * ((Kp + 127) // 128)
-        split = min(kg // 64, max(1, 512 // tiles)) if kg >= 4096 else 1
+        split = min(kg // 64, max(1, 512 // tiles)) if (kg >= 4096 and not _cfg.get("deterministic")) else 1
         if split > 1:  # long reduction, few output tiles: split-K with an fp32 workspace
             ws = zeros_f32((N, Kp), x.device)
             lib.xr_conv_igemm(dtc(x), ptr(x), ptr(pk), None, None, N, H, W, C, 1, 1, K, H, W, 1, 0, 0, kg, Kp, ptr(ws), split, None, None, None, 1, None, None, None,
@@ -862,6 +902,8 @@ class _PreluConv2d(Function):
             # dalpha partial sums are spread over `sp` rows (row tile i -> row i % sp) and folded afterwards: thousands of
             # tiles adding into the same C floats serialise at the memory side (measured: +60 us on a 100 us kernel)
             sp = _cfg["dalpha_spread"] if N * H * W >= 32 * 1024 else 1
+            if _cfg.get("deterministic"):
+                sp = _tile_rows(N * H * W, sp)
             if sp > 1:
                 dal_s = zeros_f32((sp, C), dev)
                 dal = t_a if t_a is not None else torch.empty((C,), dtype=torch.float32, device=dev)
@@ -970,8 +1012,8 @@ class _NormAct(Function):
         # BatchNorm sums are taken per image (few blocks per atomic address) and folded over the batch afterwards
         per_img = mode != "in" and N > 1 and H * W >= 16
         pg = 1
-        if per_img:  # pseudo-groups: the largest divisor of N that is <= 32
-            pg = max(d for d in range(1, min(N, 32) + 1) if N % d == 0)
+        if per_img:  # pseudo-groups: the largest divisor of N that is <= 32 (deterministic mode: one group per image)
+            pg = N if _cfg.get("deterministic") else max(d for d in range(1, min(N, 32) + 1) if N % d == 0)
             per_img = pg > 1
         pre = slink.take(x) if (slink is not None and stats and mode == "bn") else None
         if pre is not None:   # the producer already summed x and x^2 per channel (StatsLink): a convolution epilogue, or the

@@ -53,6 +53,12 @@ int xr_version(void);
 int xr_device_cus(void);
 /* tuning knobs for A/B measurements in one process: 0 = igemm LDS stage buffers (1|2), 1 = wgrad LDS stage buffers */
 int xr_tune(int knob, int value);
+/* Deterministic reductions (debugging replica divergence, bit-exact repeat tests): on != 0 makes every kernel of this library
+ * form its fp32 sums in a fixed order -- one reduction block per statistics group (hosts then use one group per image / tile and
+ * fold them in order), weight-gradient slices summed by one group, loss scalars by one block.  The host side (xrface.ops) must
+ * also give the convolution epilogues one partial row per tile (ep_spread >= row tiles) and skip split-K; slower, same results
+ * up to summation order.  Process-wide. */
+int xr_set_deterministic(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight packing.  Parameters stay fp32 nn.Parameters in the reference layouts

@@ -650,6 +650,63 @@ def test_c4_full_size_bf16_properties():
         xrface.set_compute_dtype(torch.float32)
 
 
+def test_c4_full_size_deterministic_mode_repeats_bit_for_bit():
+    """xrface.set_deterministic(True) (XR_DETERMINISTIC=1): two runs of the N = 256 bf16 C4 step on the same batch -- lockstep
+    chains, weight-gradient side stream, FlatParams in-kernel accumulation and the fused optimizers on -- give BIT-IDENTICAL losses,
+    gradients and post-step weights (every fp32 sum in a fixed order); and the mode agrees with the default mode to the default
+    mode's own run-to-run spread.  Needed before anyone debugs replica divergence across GPUs."""
+    import xrface
+    from xrface import ops, parallel
+    from xrface.model import FSRnet, model_irse
+    from xrface.steps import c4_step
+    xrface.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator(device=DEV); g.manual_seed(8)
+    lo = torch.randn(256, 3, 14, 14, device=DEV, generator=g)
+    hr = torch.nn.functional.interpolate(lo, size=(112, 112), mode="bilinear").clamp_(-1, 1).contiguous()
+    lr = torch.nn.functional.interpolate(torch.nn.functional.avg_pool2d(hr, 7), size=(112, 112), mode="bilinear").contiguous()
+
+    def run(det):
+        torch.manual_seed(31)
+        ops._drop_counter[0] = 0          # Dropout(0.5) stays ON: the counter-based mask stream restarts with the run
+        fhn = {"coarse": FSRnet.Course_SR_Network().to(DEV), "prior": FSRnet.Prior_Estimation_Network().to(DEV),
+               "encoder": FSRnet.Fine_SR_Encoder().to(DEV), "decoder": FSRnet.Fine_SR_Decoder().to(DEV)}
+        student, assistant = model_irse.IR_SE_50([112, 112]).to(DEV), model_irse.IR_SE_50([112, 112]).to(DEV)
+        teacher = model_irse.IR_SE_50([112, 112]).to(DEV).eval()
+        for p_ in teacher.parameters():
+            p_.requires_grad_(False)
+        fhn_params = [p_ for k in ("coarse", "prior", "encoder", "decoder") for p_ in fhn[k].parameters()]
+        flats = [parallel.FlatParams(fhn_params), parallel.FlatParams(student.parameters_in_execution_order()),
+                 parallel.FlatParams(assistant.parameters_in_execution_order())]
+        opts = [parallel.FusedRMSprop(f_, lr=1e-4, alpha=0.99, weight_decay=1e-5) for f_ in flats]
+        xrface.set_deterministic(det)
+        try:
+            (l1, a1), _ = c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts)
+            g1 = [f_.grad.clone() for f_ in flats]
+            (l2, a2), _ = c4_step(fhn, student, assistant, teacher, lr, hr, optimizers=opts)
+            torch.cuda.synchronize()
+        finally:
+            xrface.set_deterministic(False)
+        return (l1.item(), a1.item(), l2.item(), a2.item()), g1, [f_.flat.clone() for f_ in flats]
+
+    try:
+        la, ga, wa = run(True)
+        lb, gb, wb = run(True)
+        assert la == lb, (la, lb)
+        for name, x1, x2 in zip(("fhn", "student", "assistant"), ga, gb):
+            assert torch.equal(x1, x2), f"deterministic mode: {name} gradients of step 1 differ between two runs"
+        for name, x1, x2 in zip(("fhn", "student", "assistant"), wa, wb):
+            assert torch.equal(x1, x2), f"deterministic mode: {name} weights after two steps differ between two runs"
+        assert all(v == v for v in la)
+        ld, gd, _ = run(False)
+        cos = [float(torch.nn.functional.cosine_similarity(x1, x2, dim=0)) for x1, x2 in zip(ga, gd)]
+        print(f"[c4 N=256 bf16] deterministic vs default mode, step-1 gradient cosine: FHN {cos[0]:.4f}, student {cos[1]:.4f}, "
+              f"assistant {cos[2]:.4f}; losses {la[:2]} vs {ld[:2]}")
+        assert abs(la[0] - ld[0]) < 5e-3 * abs(ld[0]) and abs(la[1] - ld[1]) < 5e-3 * abs(ld[1])
+        assert cos[2] > 0.99 and cos[1] > 0.95 and cos[0] > 0.7, cos
+    finally:
+        xrface.set_compute_dtype(torch.float32)
+
+
 def test_c3_full_size_bf16_properties():
     """C3 at BASELINE's per-GPU batch (128, bf16: the chained residual trunks, the direct kernels with every epilogue, the
     row-walking weight gradients, the side stream): size-independent properties.  (1) on a 32-image slice the bf16 losses agree

@@ -644,6 +644,47 @@ def test_calculate_roc_default_fold_count_matches_oracle():
         calculate_roc(thresholds, e1[:600], e2[:600], same[:600], nrof_folds=300)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_deterministic_mode_unit_step_repeats_bit_for_bit(dtype):
+    """Two bottleneck_IR_SE units + a residual FSRNet block under xrface.set_deterministic(True): forward outputs, every parameter
+    gradient and the input gradient are bit-identical between two runs (one reduction block per image-group, per-tile epilogue
+    partial rows folded in order, single-group weight-gradient sums), and agree with the default mode to rounding.  In the default
+    mode the same comparison is NOT exact (fp32 atomics order), which is what makes this test meaningful."""
+    import xrface
+    from xrface import ops
+    from xrface.model.FSRnet import _Residual_Block
+    from xrface.model.model_irse import bottleneck_IR_SE
+    torch.manual_seed(11)
+    mods = torch.nn.ModuleList([bottleneck_IR_SE(64, 64, 2), bottleneck_IR_SE(64, 128, 2), _Residual_Block(64)]).to(DEV).train()
+    x = (rnd("detx", 6, 64, 40, 40) * 0.7).to(DEV)
+    gy = rnd("detg", 6, 128, 10, 10).to(DEV)
+    gz = rnd("detz", 6, 64, 40, 40).to(DEV)
+
+    def run():
+        for p_ in mods.parameters():
+            p_.grad = None
+        xg = x.clone().requires_grad_(True)
+        buf = ops.enter(xg, dtype)
+        z = mods[2].f(buf)
+        y = mods[1].f(mods[0].f(z))
+        out, mid = ops.leave(y), ops.leave(z)
+        torch.autograd.backward([out, mid], [gy.to(out.dtype), gz.to(mid.dtype)])
+        torch.cuda.synchronize()
+        return [out.detach().float().clone(), xg.grad.clone()] + [p_.grad.clone() for p_ in mods.parameters()]
+
+    xrface.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        xrface.set_deterministic(False)
+    for i, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"deterministic mode: tensor #{i} differs between two runs"
+    c = run()
+    tol = 5e-2 if dtype == torch.bfloat16 else 2e-3
+    for i, (u, v) in enumerate(zip(a, c)):
+        assert rel(u, v) < tol, (i, rel(u, v))
+
+
 def test_arcface_head_against_fp64_restatement():
     """ArcFace is absent from the reference (parity unpinned): checked against the fp64 restatement in the oracle."""
     from oracle import cpu_ref as R
