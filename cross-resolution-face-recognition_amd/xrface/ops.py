@@ -22,7 +22,8 @@ _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_
         "fuse_in_reduce": int(_os.environ.get("XR_FUSE_IN_REDUCE", "1")),
         "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")), "direct64_prelu": 1,
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0")), "f32_planes": 3,
-        "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1")), "deterministic": 0}
+        "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1")), "deterministic": 0,
+        "block_abi": int(_os.environ.get("XR_BLOCK_ABI", "1"))}
 
 
 if _os.environ.get("XR_DETERMINISTIC", "0") == "1":   # host half of the switch (see set_deterministic); _lib.load() sets the device half
@@ -1256,6 +1257,50 @@ def _conv64(x, pk, out, transposed=0, bias=None, scale=None, shift=None, alpha=N
     return out
 
 
+def _resblock_fields():
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    ptrs1 = ("w1_fwd", "w2_fwd", "w1_dgrad", "w2_dgrad", "g1", "b1", "a1", "g2", "b2", "ao", "x", "c1", "c2", "out", "mean1", "invstd1",
+             "scale1", "shift1", "mean2", "invstd2", "scale2", "shift2", "ws_fwd", "dout", "tail_red", "dx", "dc2", "dy1", "dc1", "dres",
+             "ws_bwd", "dg1", "db1", "da1", "dg2", "db2", "dao", "slabs", "dw1", "dw2")
+    ptrs2 = ("prev_c2", "prev_x", "prev_scale2", "prev_shift2", "prev_ao", "prev_tail_red", "side_stream", "fork_event")
+    return ([("N", I), ("H", I), ("W", I), ("eps", F)] + [(k, P) for k in ptrs1] + [("dw_accumulate", I), ("reserved", I)]
+            + [(k, P) for k in ptrs2])
+
+
+class _ResblockDesc(ctypes.Structure):
+    """include/xrface.h: xr_resblock_desc (field for field; the size is checked against the library once)."""
+    _fields_ = _resblock_fields()
+
+
+_desc_checked = [False]
+
+
+def _resblock_desc(**kw):
+    if not _desc_checked[0]:
+        if lib.xr_resblock_desc_size() != ctypes.sizeof(_ResblockDesc):
+            raise RuntimeError("xrface: xr_resblock_desc layout mismatch between include/xrface.h and xrface.ops")
+        _desc_checked[0] = True
+    d = _ResblockDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return d
+
+
+def _resblock_abi_ok(x):
+    """The block-level entry points (xr_resblock_fwd / xr_resblock_bwd) cover what the direct weight-gradient kernel covers."""
+    return _cfg["block_abi"] and x.shape[2] % 8 == 0 and x.shape[2] <= 112 and not _cfg.get("probe")
+
+
+def _side_for_block(dev):
+    """(side stream handle, fork event handle) for xr_resblock_bwd, or (None, None) when the weight gradients stay on the main
+    stream; the C side records the event and makes the side stream wait, _side_done() does the bookkeeping afterwards."""
+    if not (_cfg["wgrad_stream"] and _cfg["wgrad64_stream"]) or _graph["capturing"]:
+        return None, None, None
+    if _side["stream"] is None or _side["dev"] != dev:
+        _side_fork(dev)            # creates stream + event (and records the event once: a HIP event exists after its first record)
+    return _side["stream"], _side["stream"].cuda_stream, _side["ev"].cuda_event
+
+
 class _ResBlock64(Function):
     """FSRNet residual block (model/FSRnet.py:75-98) on 64 channels in bf16 as ONE op over the direct convolution kernel:
         c1 = conv1(x)                      + per-image sum / sum-of-squares of c1 in the epilogue      (no statistics pass)
@@ -1383,6 +1428,10 @@ class _ResBlock64(Function):
 
 def resblock64(x, conv1, in1, relu, conv2, in2, relu_out):
     """conv1 / conv2: xrface.nn.Conv2d (64 -> 64, 3x3, bias-free), in1 / in2: affine InstanceNorm2d, relu / relu_out: PReLU(64)."""
+    if _cfg["res_trunk"] and _resblock_abi_ok(x) and x.dtype == torch.bfloat16 and x.numel() * 2 < (1 << 31):
+        # a single application of the chained-trunk op: forward / backward are one xr_resblock_fwd / xr_resblock_bwd call each
+        return _ResTrunk64.apply(x, 1, 1, in1.eps, conv1.weight, in1.weight, in1.bias, relu.weight, conv2.weight, in2.weight,
+                                 in2.bias, relu_out.weight)
     return _ResBlock64.apply(x, conv1.weight, in1.weight, in1.bias, relu.weight, conv2.weight, in2.weight, in2.bias,
                              relu_out.weight, in1.eps)
 
@@ -1420,9 +1469,21 @@ class _ResTrunk64(Function):
 
         saved = [x]
         cur = x
+        abi = _resblock_abi_ok(x)
         for i in range(times * nb):
             b = i % nb
             g1f, b1f, a1f, g2f, b2f, aof = small[b]
+            if abi:   # one C call enqueues the five launches of the application (xr_resblock_fwd)
+                stat = torch.empty((8, N, C), **f32)
+                c1, c2, out = torch.empty_like(cur), torch.empty_like(cur), torch.empty_like(cur)
+                d_ = _resblock_desc(N=N, H=H, W=W, eps=eps, w1_fwd=pk[b][0], w2_fwd=pk[b][1], g1=g1f, b1=b1f, a1=a1f, g2=g2f, b2=b2f,
+                                    ao=aof, x=cur, c1=c1, c2=c2, out=out, mean1=stat[0], invstd1=stat[1], scale1=stat[2],
+                                    shift1=stat[3], mean2=stat[4], invstd2=stat[5], scale2=stat[6], shift2=stat[7],
+                                    ws_fwd=zeros_f32((4, N, C), dev))
+                lib.xr_resblock_fwd(ctypes.addressof(d_), stream())
+                saved += [c1, c2, *stat.unbind(0), out]
+                cur = out
+                continue
             st1 = zeros_f32((2, N, C), dev)
             c1 = _conv64(cur, pk[b][0], torch.empty_like(cur), stats=st1, tag=tag)
             mean1, invstd1, scale1, shift1 = finalize(st1, g1f, b1f)
@@ -1475,12 +1536,58 @@ class _ResTrunk64(Function):
                 dws[id(p_)] = v if id(p_) not in dws else dws[id(p_)] + v
 
         red_tail = None     # sums of the CURRENT application's tail, when they came out of the previous kernel's epilogue
+        abi = _resblock_abi_ok(x0)
         for i in range(A - 1, -1, -1):
             b = i % nb
             w1, g1, b1, a1, w2, g2, b2, ao = blocks[b]
             g1f, b1f, a1f, g2f, b2f, aof = small[b]
             c1, c2, mean1, invstd1, scale1, shift1, mean2, invstd2, scale2, shift2, _ = per[i]
             xin = x0 if i == 0 else per[i - 1][10]
+            if abi:
+                # ---- one C call for the whole application (xr_resblock_bwd): tail, both input gradients with their fused sums, both
+                # weight gradients (forked onto the side stream inside the call)
+                (t_g2, dg2), (t_b2, db2), (t_ao, dao) = small_acc(g2), small_acc(b2), small_acc(ao)
+                (t_g1, dg1), (t_b1, db1), (t_a1, da1) = small_acc(g1), small_acc(b1), small_acc(a1)
+                want1, want2 = _wanted(w1), _wanted(w2)
+                tg1, tg2 = (_direct(w1) if want1 else None), (_direct(w2) if want2 else None)
+                accum = tg1 is not None or tg2 is not None     # one flag for both targets: a fresh target then starts from zero
+                fresh = torch.zeros_like if accum else torch.empty_like
+                dw1 = (tg1 if tg1 is not None else fresh(w1, dtype=torch.float32)) if want1 else None
+                dw2 = (tg2 if tg2 is not None else fresh(w2, dtype=torch.float32)) if want2 else None
+                on_side = (dw1 is None or tg1 is not None) and (dw2 is None or tg2 is not None) and (want1 or want2)
+                side, side_h, ev_h = _side_for_block(dev) if on_side else (None, None, None)
+                split = min(256, N * H)
+                slabs = torch.empty((2 * split * 64 * 576,), **f32) if (want1 or want2) else None
+                dc2, dy1, dc1 = torch.empty_like(x0), torch.empty_like(x0), torch.empty_like(x0)
+                dres = torch.empty_like(x0) if red_tail is None else None
+                chain = i > 0
+                nxt = torch.empty_like(x0) if (chain or need_x) else None
+                nred = zeros_f32((3, N, C), dev) if chain else None
+                pi = per[i - 1] if chain else None
+                d_ = _resblock_desc(
+                    N=N, H=H, W=W, eps=0.0,
+                    w1_dgrad=_packed(w1, "dgrad", x0.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)[0] if nxt is not None else None,
+                    w2_dgrad=_packed(w2, "dgrad", x0.dtype, 64, 1, 9, 64, 64, 9, 0, 1, 576)[0],
+                    g1=g1f, b1=b1f, a1=a1f, g2=g2f, b2=b2f, ao=aof, x=xin, c1=c1, c2=c2, mean1=mean1, invstd1=invstd1, scale1=scale1,
+                    shift1=shift1, mean2=mean2, invstd2=invstd2, scale2=scale2, shift2=shift2, dout=g, tail_red=red_tail, dx=nxt,
+                    dc2=dc2, dy1=dy1, dc1=dc1, dres=dres, ws_bwd=zeros_f32((12, N, C), dev), dg1=dg1, db1=db1, da1=da1, dg2=dg2,
+                    db2=db2, dao=dao, slabs=slabs, dw1=dw1, dw2=dw2, dw_accumulate=int(accum),
+                    prev_c2=pi[1] if chain else None, prev_x=(x0 if i == 1 else per[i - 2][10]) if chain else None,
+                    prev_scale2=pi[8] if chain else None, prev_shift2=pi[9] if chain else None,
+                    prev_ao=small[(i - 1) % nb][5] if chain else None, prev_tail_red=nred, side_stream=side_h, fork_event=ev_h)
+                lib.xr_resblock_bwd(ctypes.addressof(d_), stream())
+                if side is not None:
+                    _side_done(side, (xin, c1, dc2, dc1, slabs, scale1, shift1, a1f))
+                for p_ in (g2, b2, ao, g1, b1, a1):
+                    if acc[id(p_)][0] is not None:
+                        _direct_done(p_)
+                for p_, t_, v in ((w2, tg2, dw2), (w1, tg1, dw1)):
+                    if t_ is not None:
+                        _direct_done(p_)
+                    elif v is not None:
+                        add_dw(p_, v)
+                g, red_tail = nxt, nred
+                continue
             # ---- tail: out = prelu_out(IN2(c2) + xin)
             (t_g, dg), (t_b, db), (t_a, da) = small_acc(g2), small_acc(b2), small_acc(ao)
             coef = torch.empty((3, N, C), **f32)

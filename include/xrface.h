@@ -192,6 +192,77 @@ int xr_unpack_wgrad(const float* packed, float* dst, int A1, int A2, int taps, i
                     int64_t sa1, int64_t sa2, int64_t st, int64_t sb, int accumulate, int nslices, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Block-level entry points (SURVEY 8b "fused xr_resblock_{fwd,bwd}"): ONE call enqueues every launch of an FSRNet residual
+ * block application (model/FSRnet.py:75-98: out = PReLU_out(IN2(conv2(PReLU(IN1(conv1(x))))) + x)); 64 channels, bf16 NHWC
+ * tensors [N][H][W][64], W % 8 == 0 and W <= 112 for the backward (direct weight-gradient kernel).
+ *   fwd: conv1 (+ statistics of c1) -> finalize -> conv2 with IN1 + PReLU on load (+ statistics of c2) -> finalize ->
+ *        out = prelu_out(c2 * scale2 + shift2 + x).  Writes c1, c2, out and the eight [N][64] statistics / coefficient buffers.
+ *   bwd: tail backward (reduce + coefficients + apply; with tail_red only coefficients + a two-input apply) -> conv2 input
+ *        gradient with the IN1 + PReLU sums in its epilogue -> coefficients -> apply -> conv1 input gradient + residual-branch
+ *        gradient (with prev_*: chained into the previous application's tail, xr_conv64_direct_tailred) -> both weight gradients
+ *        (on side_stream after fork_event when given; the caller joins the streams).  dg / db / da targets are accumulated (+=).
+ * Workspaces are caller-owned: ws_fwd 4*N*64 floats ZEROED; ws_bwd 12*N*64 floats, the first 6*N*64 ZEROED; prev_tail_red 3*N*64
+ * ZEROED; slabs 2 * min(256, N*H) * 64 * 576 floats; dc2 / dy1 / dc1 / dres tensors laid out like x. */
+typedef struct xr_resblock_desc {
+  int N, H, W;
+  float eps;
+  const void* w1_fwd;      /* [64][576] bf16 forward packs (xr_pack_weight) */
+  const void* w2_fwd;
+  const void* w1_dgrad;    /* input-gradient packs (backward) */
+  const void* w2_dgrad;
+  const float* g1;         /* IN1 gamma / beta, PReLU slope [64] */
+  const float* b1;
+  const float* a1;
+  const float* g2;         /* IN2 gamma / beta, output PReLU slope [64] */
+  const float* b2;
+  const float* ao;
+  const void* x;           /* block input */
+  void* c1;                /* conv1 output (saved) */
+  void* c2;                /* conv2 output (saved) */
+  void* out;               /* block output (fwd) */
+  float* mean1;            /* [N][64] each: written by fwd, read by bwd */
+  float* invstd1;
+  float* scale1;
+  float* shift1;
+  float* mean2;
+  float* invstd2;
+  float* scale2;
+  float* shift2;
+  float* ws_fwd;
+  /* ---- backward only */
+  const void* dout;        /* gradient of out -- or, with tail_red, already dz = dout * prelu'(tail) */
+  const float* tail_red;   /* [3][N][64] sums over (dz, c2) delivered by the next application's chained conv1 input gradient, or NULL */
+  void* dx;                /* input gradient (NULL: not needed); chained: the previous application's dz */
+  void* dc2;               /* workspace tensors */
+  void* dy1;
+  void* dc1;
+  void* dres;              /* tail pre-activation gradient (unused with tail_red) */
+  float* ws_bwd;
+  float* dg1;              /* [64] each, accumulated; NULL: skipped */
+  float* db1;
+  float* da1;
+  float* dg2;
+  float* db2;
+  float* dao;
+  float* slabs;
+  float* dw1;              /* [64][64][3][3] parameter-layout targets (NULL: that weight gradient is skipped) */
+  float* dw2;
+  int dw_accumulate;       /* 1: dw += , 0: dw = */
+  int reserved;
+  const void* prev_c2;     /* chaining (all or none): the previous application's c2, input x, scale2 / shift2 [N][64], output slope */
+  const void* prev_x;
+  const float* prev_scale2;
+  const float* prev_shift2;
+  const float* prev_ao;
+  float* prev_tail_red;    /* [3][N][64], zeroed by the caller: becomes the previous application's tail_red */
+  void* side_stream;       /* hipStream_t for the weight gradients, or NULL (main stream) */
+  void* fork_event;        /* hipEvent_t recorded on the main stream before the fork */
+} xr_resblock_desc;
+int xr_resblock_desc_size(void);
+int xr_resblock_fwd(const xr_resblock_desc* d, void* stream);
+int xr_resblock_bwd(const xr_resblock_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Normalisation / activation family.  Tensors are [G][rows][C] (G groups of `rows` pixels):
  * BatchNorm2d/1d: G = 1, rows = N*H*W (model_irse.py:56-60,141,144,148; model/resnet.py:24,27,159,167,173);
  * InstanceNorm2d: G = N, rows = H*W (model/FSRnet.py:81,87,112,115,319,347,385,434);
