@@ -394,14 +394,34 @@ def secondary_workloads(dev, c4_batch=256, c3_batch=128, world=1, rank=0, cpu_le
                 chk = f_.flat[:4096].clone()
                 dist.broadcast(chk, 0)
                 assert torch.equal(chk, f_.flat[:4096]), "C3 replicas diverged: gradient all-reduce is broken"
+        ms_eager = ms
+        if world == 1:
+            # the same step as ONE HIP-graph replay (xrface.graph.GraphedStep, single stream): at this batch the side stream buys the
+            # FHN step nothing and the prior / encoder sub-networks (28 x 28 maps, ~600 launches of 10-25 us) are host-paced
+            from xrface.graph import GraphedStep
+            lbuf = torch.zeros(4, device=dev)
+
+            def c3g(lr_, hr_, hm_, par_):
+                l_, _ = steps.fhn_step_fused(fhn, lr_, hr_, hm_, par_, optimizers=opts)
+                lbuf.copy_(torch.stack([l_[k].float() for k in ("coarse", "encoder", "prior", "decoder")]))
+                return lbuf
+            gs = GraphedStep(c3g, [lr, hr, hm, par], warmup=2)
+            ms_g, _ = _timed(lambda: gs(lr, hr, hm, par), 2, 7)
+            gs.close()
+            del gs
+            ms = min(ms, ms_g)
         tf = 3.0 * FHN_FWD_GFLOP * c3_batch / ms
         ent = {"workload": "C3 (BASELINE configs[2], per-GPU shape): root FHN coarse -> {prior, encoder} -> decoder, mse97 + landmark + "
                            "parsing losses, per-network gradients, RMSprop x4"
                            + (", data parallel: four bucketed gradient all-reduces inside the step" if world > 1 else ""),
                "n_gpus": world, "per_gpu_batch": c3_batch, "dtype": "bf16", "ms_per_step": round(ms, 2),
+               "ms_per_step_eager": round(ms_eager, 2),
                "images_per_s": round(c3_batch * world / ms * 1e3, 1),
                "algorithmic_tflop_per_step": round(3.0 * FHN_FWD_GFLOP * c3_batch * world / 1e3, 2), "achieved_tflops": round(tf * world, 1),
                "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4)}
+        if world == 1:
+            ent["ms_per_step_graph"] = round(ms_g, 2)
+            ent["launch"] = "one HIP-graph replay per step" if ms_g <= ms_eager else "eager launches"
         rf = step_roofline("c3", ms, c3_batch)
         if rf is not None:
             ent["roofline"] = rf

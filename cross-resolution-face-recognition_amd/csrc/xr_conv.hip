@@ -498,11 +498,18 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
     }
     if (m < 0) continue;
     const out_t* sp = stage + row * PITCH + ch * 8;
-    out_t* dp = out + (size_t)m * p.ldo + ncol;
+    size_t oo = (size_t)m * p.ldo + ncol;   // element offset of this chunk in out / ep_src / ep_add / ep2_out
+    if (p.d2s_c != 0) {   // depth-to-space: column block -> sub-pixel (a, b) of the 2x up-sampled grid
+      const int cl = fdiv(p.fd_d2s, ncol), cch = ncol - cl * p.d2s_c;
+      const int n_ = fdiv(p.fd_howo, m), rem_ = m - n_ * (int)p.fd_howo.d;
+      const int ho_ = fdiv(p.fd_wo, rem_), wo_ = rem_ - ho_ * (int)p.fd_wo.d;
+      oo = ((size_t)(n_ * 2 * p.Ho + 2 * ho_ + (cl >> 1)) * (2 * p.Wo) + 2 * wo_ + (cl & 1)) * p.d2s_c + cch;
+    }
+    out_t* dp = out + oo;
     if (ep) {
       float d[8], yv[8], o[8];
       ld8(sp, d);
-      ld8(ep_src + (size_t)m * p.ldo + ncol, yv);
+      ld8(ep_src + oo, yv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const bool neg = yv[e] <= 0.f;
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
       float d[8], xv[8];
       ld8(sp, d);
       if (ep_src != nullptr) {
-        ld8(ep_src + (size_t)m * p.ldo + ncol, xv);
+        ld8(ep_src + oo, xv);
       } else {   // statistics of the output itself (sum, sum of squares) for a BatchNorm that follows
 #pragma unroll
         for (int e = 0; e < 8; ++e) xv[e] = d[e];
@@ -532,12 +539,12 @@ __global__ __launch_bounds__(NT, (FAST && MODE == 0 && DMA == 0) ? (BM > 128 ? 2
       ld8(sp, d);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = d[e] > 0.f ? d[e] : d[e] * alv[e];
-      st8(out2 + (size_t)m * p.ldo + ncol, o);
+      st8(out2 + oo, o);
     }
     if (p.ep_add != nullptr) {   // gradient of an identity branch summed here instead of by a separate elementwise pass
       float d[8], av[8];
       ld8(sp, d);
-      ld8(reinterpret_cast<const out_t*>(p.ep_add) + (size_t)m * p.ldo + ncol, av);
+      ld8(reinterpret_cast<const out_t*>(p.ep_add) + oo, av);
 #pragma unroll
       for (int e = 0; e < 8; ++e) d[e] += av[e];
       st8(dp, d);
@@ -639,6 +646,7 @@ int launch_igemm_f(IgemmP& p, hipStream_t st) {
   p.fd_wq = make_fd((unsigned)(p.Wo / p.stride > 0 ? p.Wo / p.stride : 1));
   p.fd_tn = make_fd((unsigned)p.tiles_n);
   p.fd_st = make_fd((unsigned)p.stride);
+  p.fd_d2s = make_fd((unsigned)(p.d2s_c > 0 ? p.d2s_c : 1));
   int gy = 1;
   if (p.ws != nullptr) {
     const int nk = p.Kg / BKT;
@@ -1602,6 +1610,63 @@ extern "C" int xr_conv_igemm(int dtype, const void* in, const void* w, const flo
   }
   if (wide) return transposed ? launch_igemm<1, 128, 128, 2, true>(p, st) : launch_igemm<1, 128, 128, 2, false>(p, st);
   return transposed ? launch_igemm<1, 128, 64, 4, true>(p, st) : launch_igemm<1, 128, 64, 4, false>(p, st);
+}
+
+// ---- stride-2 3x3 input gradient as ONE dense stride-1 2x2 gather (xr_conv_dgrad_s2)
+namespace {
+// dst[q][(cls * C2 + c)][t * Kp + k] = plane q of w[k][c][r][s] for the window tap t = 2 dr + ds that sub-pixel class cls = 2 a + b
+// can see (a = 0: dr = 0 -> r = 1; a = 1: dr = 0 -> r = 2, dr = 1 -> r = 0; the same for b / ds / s), 0 elsewhere
+__global__ void pack_s2dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ dst, int nplanes, int K, int C, int Kp, int C2,
+                                    int Kg, int64_t plane) {
+  const int64_t total = (int64_t)4 * C2 * Kg;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(i / Kg), col = (int)(i - (int64_t)row * Kg);
+    const int cls = row / C2, c = row - cls * C2;
+    const int tp = col / Kp, k = col - tp * Kp;
+    float v = 0.f;
+    if (c < C && k < K && tp < 4) {
+      const int a = cls >> 1, b = cls & 1, dr = tp >> 1, ds = tp & 1;
+      const int r = a ? (dr ? 0 : 2) : (dr ? -1 : 1), s_ = b ? (ds ? 0 : 2) : (ds ? -1 : 1);
+      if (r >= 0 && s_ >= 0) v = w[(((size_t)k * C + c) * 3 + r) * 3 + s_];
+    }
+    for (int q = 0; q < nplanes; ++q) {
+      const bf16_t h = f2bf(v);
+      dst[(int64_t)q * plane + i] = h;
+      v -= bf2f(h);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int xr_pack_dgrad_s2(const float* w, void* dst, int nplanes, int K, int C, int Kp, int C2, int Kg, void* stream) {
+  XR_CHECK_ARG(w && dst && nplanes >= 1 && nplanes <= 3 && K > 0 && C > 0 && Kp >= K && C2 >= C && Kp % 8 == 0 && C2 % 8 == 0,
+               "xr_pack_dgrad_s2: bad arguments");
+  XR_CHECK_ARG(Kg % 64 == 0 && Kg >= 4 * Kp, "xr_pack_dgrad_s2: Kg must be a multiple of 64 and >= 4 * Kp");
+  const int64_t total = (int64_t)4 * C2 * Kg;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(pack_s2dgrad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)dst, nplanes, K, C, Kp, C2, Kg,
+                     total);
+  XR_CHECK_LAUNCH("xr_pack_dgrad_s2");
+  return XR_OK;
+}
+
+extern "C" int xr_conv_dgrad_s2(int dtype, const void* dy, const void* wpack, void* dx, int N, int Ho, int Wo, int Kp, int C2, int Kg,
+                                const void* ep_src, const float* ep_alpha4, float* ep_dalpha, int ep_spread, float* ep_red,
+                                const void* ep_add, void* stream) {
+  XR_CHECK_ARG(dtype == XR_BF16 || dtype == XR_F32 || dtype == XR_F32X2, "xr_conv_dgrad_s2: bad dtype %d", dtype);
+  XR_CHECK_ARG(dy && wpack && dx && N > 0 && Ho > 0 && Wo > 0 && Kp > 0 && C2 > 0, "xr_conv_dgrad_s2: null pointer / non-positive dimension");
+  XR_CHECK_ARG(Kp % 8 == 0 && C2 % 8 == 0 && Kg % 64 == 0 && Kg >= 4 * Kp, "xr_conv_dgrad_s2: Kp / C2 multiples of 8, Kg >= 4 * Kp");
+  XR_CHECK_ARG((long long)N * Ho * Wo < (1ll << 29), "xr_conv_dgrad_s2: too many pixels");
+  XR_CHECK_ARG(ep_src == nullptr || ep_red != nullptr || (ep_alpha4 && ep_dalpha), "xr_conv_dgrad_s2: PReLU-backward epilogue needs alpha and dalpha");
+  XR_CHECK_ARG(ep_add == nullptr || (ep_src == nullptr && ep_red == nullptr), "xr_conv_dgrad_s2: ep_add excludes the other epilogues");
+  IgemmP p{dy, (const bf16_t*)wpack, nullptr, dx, N, Ho, Wo, Kp, Ho, Wo, 4 * C2, 2, 2, 1, 0, Kg, 4 * C2,
+           N * Ho * Wo, 0, 0, 0, 0, nullptr, 0, {}, {}, {}, {}, {}, {}, {}, {}, 0, 0, ep_src, ep_alpha4, ep_dalpha, ep_spread > 0 ? ep_spread : 1, nullptr, ep_red, ep_add, g_tune[4]};
+  p.d2s_c = C2;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == XR_BF16) return launch_igemm<0, 128, 128, 2, false>(p, st);
+  if (dtype == XR_F32X2) return launch_igemm<2, 128, 128, 2, false>(p, st);
+  return launch_igemm<1, 128, 128, 2, false>(p, st);
 }
 
 extern "C" int xr_conv_wgrad(int dtype, const void* in, const void* dy, float* dwp, int N, int H, int W, int C, int Ho,

@@ -50,6 +50,11 @@ struct IgemmP {
   // fused gradient sum: out += ep_add (same layout as out) -- the gradient arriving through an identity branch of the same input
   const void* ep_add;
   int prio;  // raise wave priority around the MFMA clusters (tuning knob 4)
+  // depth-to-space output (xr_conv_dgrad_s2; 4-wave kernel only): the GEMM's K = 4 * d2s_c output columns are (class, channel)
+  // with class = 2 a + b, and row m = (n, ho, wo) of the [N][Ho][Wo] grid writes channel c of class (a, b) to pixel
+  // (2 ho + a, 2 wo + b) of an [N][2 Ho][2 Wo][d2s_c] tensor; ep_src / ep_add / ep2_out follow the same addressing.  0 = off.
+  int d2s_c;
+  FastDiv fd_d2s;
 };
 
 // decode flat pixel index -> (pixel base n*H*W, oh0, ow0) of the gather origin

@@ -23,7 +23,7 @@ _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_
         "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")), "direct64_prelu": 1,
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0")), "f32_planes": 3,
         "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1")), "deterministic": 0,
-        "block_abi": int(_os.environ.get("XR_BLOCK_ABI", "1"))}
+        "block_abi": int(_os.environ.get("XR_BLOCK_ABI", "1")), "conv1x1_subsample": int(_os.environ.get("XR_CONV1X1_SUBSAMPLE", "0")), "dgrad_s2": int(_os.environ.get("XR_DGRAD_S2", "0"))}
 
 
 if _os.environ.get("XR_DETERMINISTIC", "0") == "1":   # host half of the switch (see set_deterministic); _lib.load() sets the device half
@@ -502,6 +502,38 @@ def _packed(w, kind, dtype, A1, A2, taps, B, Bp, sa1, sa2, st, sb):
     return pk, kg
 
 
+def _dgrad_s2_ok(x_shape, w, stride, pad, Ho, Wo):
+    """3x3 / stride 2 / pad 1 with even input extent: the dense 2x2-window input gradient (xr_conv_dgrad_s2) applies.  OFF by default
+    (XR_DGRAD_S2=1): isolated at batch 256 it ties the class-mode strided gather on all four IR-SE-50 stage openings (64 ch @112: 287
+    vs 257 us; 128 @56: 189 vs 196; 256 @28: 159 vs 158; 512 @14: 134 vs 142) -- 16/9 of the MACs on the 4-wave kernel cost what the
+    dense gather saves -- and the C2 step did not move (19.43 vs 19.30 ms); it would need the 8-wave kernel's rate to pay."""
+    N, H, W, Cp = x_shape
+    K, C, R, S = w.shape
+    return (_cfg["dgrad_s2"] and R == 3 and S == 3 and stride == 2 and pad == 1 and H % 2 == 0 and W % 2 == 0 and Ho * 2 == H
+            and Wo * 2 == W and C % 8 == 0 and K % 8 == 0)
+
+
+def _packed_s2(w, dtype):
+    """[planes][4 * C][4 * K] pack of a [K][C][3][3] parameter for xr_conv_dgrad_s2 (cached on the parameter like _packed; not part of
+    the batched refresh: four small launches per network and step)."""
+    cache = w.__dict__.setdefault("_xr_pack", {})
+    planes = _cfg["f32_planes"] if dtype == torch.float32 else 1
+    key = ("s2dgrad", dtype, planes)
+    tag = _pack_tag(w)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1], hit[2]
+    K, C = w.shape[0], w.shape[1]
+    kg = kg_of(4, K)
+    pk = hit[1] if hit is not None else torch.empty((planes, 4 * C, kg), dtype=torch.bfloat16, device=w.device)
+    wd = w.detach()
+    if wd.dtype != torch.float32 or not wd.is_contiguous():
+        wd = wd.float().contiguous()
+    lib.xr_pack_dgrad_s2(ptr(wd), ptr(pk), planes, K, C, K, C, kg, stream())
+    cache[key] = (tag, pk, kg)
+    return pk, kg
+
+
 def _wgrad_split(M, K, kg):
     tiles = ((K + 127) // 128) * ((kg + 127) // 128) if (K > 64 or kg <= 128) else ((kg + 255) // 256)
     steps = (M + 63) // 64
@@ -719,7 +751,15 @@ class _Conv2d(Function):
                     dpass = dpass.to(x.dtype)
             add_in_kernel = dpass is not None and red is None and C % 8 == 0
             pe = _probe_begin(("dgrad", Cp, K, H, W, R, stride))
-            if red is not None and dpass is None and direct64_ok(x, w, stride, pad) and Kp == 64:
+            if _dgrad_s2_ok(x.shape, w, stride, pad, Ho, Wo) and K == Kp and C == Cp:
+                # 3x3 / stride 2: one dense 2x2-window GEMM with a depth-to-space epilogue (xr_conv_dgrad_s2); the BatchNorm-backward
+                # partial sums then come per (spread row, sub-pixel class) -- folded like any other partial rows
+                pk2, kg2 = _packed_s2(w, x.dtype)
+                if red is not None:
+                    red = zeros_f32((3, sp_ * 4, C), x.device)
+                lib.xr_conv_dgrad_s2(dtc(x), ptr(dy), ptr(pk2), ptr(dx), N, Ho, Wo, Kp, Cp, kg2, ptr(link.x) if red is not None else None,
+                                     None, None, sp_, ptr(red), ptr(dpass) if add_in_kernel else None, stream())
+            elif red is not None and dpass is None and direct64_ok(x, w, stride, pad) and Kp == 64:
                 # 64 -> 64 3x3 (conv1 of the IR stage-1 blocks, model_irse.py:56-59): the direct kernel with the BatchNorm-backward
                 # sums in its epilogue -- sum d and sum d * x per image (identity transform: scale 1, shift 0, no slope), folded over
                 # the batch by xr_norm_bwd_coeffs like the spread partials of the implicit GEMM
@@ -910,11 +950,24 @@ class _PreluConv2d(Function):
                 dal = t_a if t_a is not None else torch.empty((C,), dtype=torch.float32, device=dev)
             else:
                 dal_s = dal = t_a if t_a is not None else zeros_f32((C,), dev)
-            pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
             dy1 = torch.empty_like(y1)
             pe = _probe_begin(("dgrad", Cp, K, H, W, R, stride))
-            lib.xr_conv_igemm(dtc(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
-                              0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, None, stream())
+            if _dgrad_s2_ok(y1.shape, w, stride, pad, Ho, Wo) and K == Kp:
+                # stage-opening unit: the strided input gradient as one dense 2x2-window GEMM with a depth-to-space epilogue; dalpha
+                # partials come per (spread row, sub-pixel class) and are folded over both
+                pk, kg = _packed_s2(w, y1.dtype)
+                dal_s = zeros_f32((sp, 4 * C), dev)
+                if t_a is None:
+                    dal = torch.empty((C,), dtype=torch.float32, device=dev)
+                else:
+                    dal = t_a
+                lib.xr_conv_dgrad_s2(dtc(y1), ptr(dy), ptr(pk), ptr(dy1), N, Ho, Wo, Kp, Cp, kg, ptr(y1), ptr(al.repeat(4)), ptr(dal_s), sp,
+                                     None, None, stream())
+                sp *= 4
+            else:
+                pk, kg = _packed(w, "dgrad", y1.dtype, C, 1, R * S, K, Kp, R * S, 0, 1, C * R * S)
+                lib.xr_conv_igemm(dtc(y1), ptr(dy), ptr(pk), None, ptr(dy1), N, Ho, Wo, Kp, H, W, C, R, S, stride, pad, 1, kg, Cp, None,
+                                  0, ptr(y1), ptr(al), ptr(dal_s), sp, None, None, None, stream())
             if pe is not None:
                 pe.record()
             if sp > 1:
@@ -964,6 +1017,13 @@ class StatsLink:
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, stats_link=None):
+    if stride > 1 and w.shape[2] == 1 and w.shape[3] == 1 and pad == 0 and _cfg["conv1x1_subsample"]:
+        # 1x1 / stride s (the shortcut convolutions of the stage transitions, model_irse.py:54, model/resnet.py:196): sub-sample first,
+        # then a plain stride-1 1x1 GEMM -- its input gradient is a dense GEMM + a zero-filling scatter and its weight gradient the
+        # forward-gather fast path.  OFF by default (XR_CONV1X1_SUBSAMPLE=1): the strided forms look terrible in the in-step per-site
+        # table (18-140 TFLOP/s, 0.45 ms per C2 step) but that time is CU sharing with the side stream -- the interleaved A/B of the
+        # whole step showed no difference (19.43 vs 19.44 ms)
+        x, stride = subsample(x, stride), 1
     return _Conv2d.apply(x, w, b, stride, pad, None, None, stats_link)
 
 

@@ -117,6 +117,19 @@ int xr_conv_igemm(int dtype, const void* in, const void* w, const float* bias, v
  * and each group only visits the taps it can see (no multiply-by-zero work). */
 int xr_bias_cast(int dtype, const float* ws, const float* bias, void* out, int64_t M, int K, int ld, void* stream);
 
+/* Input gradient of a 3x3 / stride 2 / pad 1 convolution (conv2 of every stage-opening bottleneck_IR(_SE), model_irse.py:60;
+ * model/resnet.py:24) as ONE dense stride-1 implicit GEMM instead of the strided transposed gather: a 2x2 window of
+ * dy [N][Ho][Wo][Kp] feeds the four sub-pixel classes (a, b) of dx [N][2 Ho][2 Wo][C2] at once (class (0,0) sees 1 tap of the 3x3
+ * kernel, (0,1) and (1,0) two, (1,1) four: the pack holds zeros for the other window positions, 16/9 of the algorithmic MACs at
+ * the dense kernel's rate), and the epilogue scatters the 4 * C2 GEMM columns depth-to-space.  wpack: xr_pack_dgrad_s2 of the
+ * convolution's [K][C][3][3] parameter, [nplanes][4 * C2][Kg], Kg >= 4 * Kp.  Epilogue fusions as xr_conv_igemm, addressed on dx:
+ * ep_src + ep_alpha4 ([4 * C2]: alpha repeated per class) + ep_dalpha [ep_spread][4 * C2] (fold the 4 classes with
+ * xr_reduce_groups(G = 4 * ep_spread)); ep_red [3][ep_spread][4 * C2] (= [3][4 * ep_spread][C2]); ep_add. */
+int xr_pack_dgrad_s2(const float* w, void* dst, int nplanes, int K, int C, int Kp, int C2, int Kg, void* stream);
+int xr_conv_dgrad_s2(int dtype, const void* dy, const void* wpack, void* dx, int N, int Ho, int Wo, int Kp, int C2, int Kg,
+                     const void* ep_src, const float* ep_alpha4, float* ep_dalpha, int ep_spread, float* ep_red,
+                     const void* ep_add, void* stream);
+
 /* Weights-stationary direct convolution for the 64 -> 64 channel 3x3 / stride 1 / pad 1 bf16 layers (model/FSRnet.py:79,85: every
  * FSRNet body layer; model_irse.py:59 and model/resnet.py:9-12 stage 1).  Same result as xr_conv_igemm(XR_BF16, ..., C = K = 64,
  * R = S = 3, stride 1, pad 1, transposed) on the same weight pack (wpack = [64][576] bf16, one plane; for transposed != 0 the

@@ -107,6 +107,40 @@ def test_conv2d_two_plane_fp32_mode(case):
     assert min(errs["fp32x2"]) > 1.5 * max(errs[torch.float32]) or max(errs["fp32x2"]) < 2e-6, errs
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 64, 20, 12, 64), (2, 128, 16, 16, 128), (2, 64, 8, 8, 128)])
+def test_optional_strided_conv_forms(shape, dtype):
+    """Two alternative forms of the stage-opening layers, off by default because they measured no faster, kept correct:
+    the 3x3 / stride-2 input gradient as one dense 2x2-window GEMM with a depth-to-space epilogue (xr_conv_dgrad_s2; PReLU-backward
+    and BatchNorm-backward epilogues addressed on the up-sampled grid) and the 1x1 / stride-2 shortcut convolution as sub-sample +
+    stride-1 GEMM.  A bottleneck_IR_SE stage opening (model_irse.py:69-91) with both forms on against the default forms."""
+    import copy
+    import xrface
+    from xrface import ops
+    from xrface.model.model_irse import bottleneck_IR_SE
+    n, cin, h, w, depth = shape
+    xrface.set_compute_dtype(dtype)
+    try:
+        torch.manual_seed(9)
+        blk0 = bottleneck_IR_SE(cin, depth, 2).to(DEV).train()
+        x0 = rnd(f"s2f{shape}", n, cin, h, w)
+        res = {}
+        for mode in (0, 1):
+            ops._cfg["dgrad_s2"] = ops._cfg["conv1x1_subsample"] = mode
+            blk = copy.deepcopy(blk0)
+            x = x0.to(DEV).requires_grad_(True)
+            out = blk(x)
+            out.square().mean().backward()
+            torch.cuda.synchronize()
+            res[mode] = [out.detach().float().cpu(), x.grad.cpu()] + [p.grad.cpu() for p in blk.parameters()]
+        tol = 2e-3 if dtype == torch.float32 else 8e-2
+        for a, b in zip(res[1], res[0]):
+            assert rel(a, b) < tol, rel(a, b)
+    finally:
+        ops._cfg["dgrad_s2"] = ops._cfg["conv1x1_subsample"] = 0
+        xrface.set_compute_dtype(torch.float32)
+
+
 CONV8_CASES = [
     # N, C, H, W, K, R, stride, pad, bias  -- the 8-wave 256x256 kernel forced on (xr_tune knob 7 = 2)
     (2, 64, 14, 14, 256, 3, 1, 1, False),    # 392 rows: one full + one ragged row tile
