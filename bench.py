@@ -586,6 +586,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--c4-batch", type=int, default=256, help="per-GPU batch of the secondary C4 step")
     ap.add_argument("--c3-batch", type=int, default=128, help="per-GPU batch of the secondary C3 step")
+    ap.add_argument("--secondary-timeout", type=float, default=420.0, help="N > 1: seconds the data-parallel secondary steps may take")
     ap.add_argument("--all-sites", action="store_true", help="report every conv launch site in `kernels`, not the top 8")
     args = ap.parse_args()
 
@@ -727,6 +728,19 @@ def main():
         # N > 1: EVERY rank runs the data-parallel C4 / C3 steps (they hold the gradient all-reduces); rank 0 reports them
         del model, flat, opt, reducer
         torch.cuda.empty_cache()
+        if world > 1:
+            # the secondary steps hold collectives: if one rank fails or stalls the others would wait for ever and the headline
+            # measured above would be lost with them -- a watchdog prints it (without `secondary`) and ends the process
+            import threading
+
+            def _watchdog():
+                if line is not None:
+                    line["secondary"] = [{"error": f"secondary workloads did not finish within {args.secondary_timeout} s on {world} ranks"}]
+                    print(json.dumps(line), flush=True)
+                os._exit(0)
+            wd = threading.Timer(args.secondary_timeout, _watchdog)
+            wd.daemon = True
+            wd.start()
         try:
             with torch.cuda.stream(hp):      # same stream set-up as the headline: the side work yields to the critical path
                 sec = secondary_workloads(dev, c4_batch=args.c4_batch, c3_batch=args.c3_batch, world=world, rank=rank,
@@ -736,6 +750,8 @@ def main():
             sec = [{"error": f"{type(e).__name__}: {e}"[:300]}]
         if line is not None:
             line["secondary"] = sec
+    if world > 1 and not args.no_secondary and bf:
+        wd.cancel()
     if line is not None:
         print(json.dumps(line), flush=True)
     if world > 1:

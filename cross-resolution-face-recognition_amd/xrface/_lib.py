@@ -99,8 +99,23 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw handle of the current stream of the current device.  (torch.cuda.current_stream() builds a Stream object through
+    several Python layers: ~4 us, once per kernel launch -- 10 % of the host's enqueue time of a training step.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+def stream_of(device_index: int):
+    """Raw handle of the current stream of device ``device_index``."""
+    if _raw_stream is not None:
+        return _raw_stream(device_index)
+    return torch.cuda.current_stream(device_index).cuda_stream
 
 
 def dt(t) -> int:

@@ -13,7 +13,7 @@ import weakref
 import torch
 from torch.autograd import Function
 
-from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, XR_F32X2, dt, lib, ptr, stream
+from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU, ACT_TANH, XR_BF16, XR_F32, XR_F32X2, dt, lib, ptr, stream, stream_of
 
 EPS = 1e-5
 import os as _os
@@ -137,7 +137,7 @@ _graph = {"capturing": False, "tick": None, "tick_ref": 0}
 
 
 def _zpool_of(device):
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, stream_of(device.index if device.index is not None else torch.cuda.current_device()))
     zp = _zpools.get(key)
     if zp is None:
         zp = _zpools[key] = _ZeroPool()
@@ -1079,8 +1079,7 @@ class _NormAct(Function):
         pre = slink.take(x) if (slink is not None and stats and mode == "bn") else None
         if pre is not None:   # the producer already summed x and x^2 per channel (StatsLink): a convolution epilogue, or the
             pre, piv = pre    # elementwise pass that wrote x (then relative to a pivot per partial)
-            mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
-            scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
+            mean, invstd, scale, shift = torch.empty((4, G, C), **f32).unbind(0)
             upd = rmean is not None
             lib.xr_norm_finalize_pivot(ptr(pre), ptr(piv), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                        ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
@@ -1096,8 +1095,7 @@ class _NormAct(Function):
                 sums = zeros_f32((2, G, C), dev)
                 piv = torch.empty((G, C), **f32)
                 lib.xr_group_stats_pivot(dt(x), ptr(x), ptr(sums), ptr(piv), G, rows, C, stream())
-            mean, invstd = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
-            scale, shift = torch.empty((G, C), **f32), torch.empty((G, C), **f32)
+            mean, invstd, scale, shift = torch.empty((4, G, C), **f32).unbind(0)
             upd = mode == "bn" and rmean is not None
             lib.xr_norm_finalize_pivot(ptr(sums), ptr(piv), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                        ptr(rmean) if upd else None, ptr(rvar) if upd else None, G, rows, C, eps, momentum,
@@ -1819,8 +1817,7 @@ class _BnSeAdd(Function):
         sums_n = zeros_f32((2, N, C), dev)
         lib.xr_group_stats(dt(y), ptr(y), ptr(sums_n), N, HW, C, stream())
         gm, bt = _c(gamma.detach().float()), _c(beta.detach().float())
-        mean, invstd = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
-        a, b = torch.empty((1, C), **f32), torch.empty((1, C), **f32)
+        mean, invstd, a, b = torch.empty((4, 1, C), **f32).unbind(0)
         if training:
             if _cfg["fold_finalize"]:   # per-image sums folded over the batch in the same launch
                 lib.xr_norm_finalize(ptr(sums_n), ptr(gm), ptr(bt), ptr(mean), ptr(invstd), ptr(a), ptr(b), ptr(rmean), ptr(rvar),
@@ -1835,9 +1832,8 @@ class _BnSeAdd(Function):
             mean = rmean.detach().float().reshape(1, C)
             invstd = torch.rsqrt(rvar.detach().float() + eps).reshape(1, C)
         w1f, w2f = _c(w1.detach().float()), _c(w2.detach().float())
-        pooled = torch.empty((N, C), **f32)
-        hidden, s = torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
-        cA, cB = torch.empty((N, C), **f32), torch.empty((N, C), **f32)
+        pooled, s, cA, cB = torch.empty((4, N, C), **f32).unbind(0)
+        hidden = torch.empty((N, Cr), **f32)
         lib.xr_bnse_fwd(ptr(sums_n[0]), ptr(a), ptr(b), ptr(w1f), ptr(w2f), ptr(pooled), ptr(hidden), ptr(s), ptr(cA), ptr(cB), N, C,
                         Cr, HW, stream())
         sc = None if shortcut is None else _c(shortcut)
@@ -1873,8 +1869,9 @@ class _BnSeAdd(Function):
         if red is None:
             red = zeros_f32((3, N, C), dev)  # red[0] = S1 = sum dout, red[1] = S2 = sum dout*y   (per image)
             lib.xr_affine_act_bwd_reduce(dt(y), ptr(y), None, None, None, None, ACT_NONE, ptr(dout), ptr(red), N, HW, C, 1, stream())
-        dpre2, dhid, dp = torch.empty((N, C), **f32), torch.empty((N, Cr), **f32), torch.empty((N, C), **f32)
-        coef = torch.empty((3, N, C), **f32)
+        dhid = torch.empty((N, Cr), **f32)
+        big = torch.empty((5, N, C), **f32)      # dpre2, dp, coef[3]: one allocation
+        dpre2, dp, coef = big[0], big[1], big[2:]
         t_g, t_b = _direct(p_g), _direct(p_b)
         need_g, need_b = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dgamma = (t_g if t_g is not None else zeros_f32((C,), dev)) if need_g else None
