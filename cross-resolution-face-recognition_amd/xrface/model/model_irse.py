@@ -101,6 +101,8 @@ class bottleneck_IR_SE(bottleneck_IR):
 
     def f(self, x):
         rl = self.res_layer
+        if not isinstance(self.shortcut_layer, Sequential) and ops.ir_se_unit_ok(x, self) and self.shortcut_layer.stride in (1, (1, 1)):
+            return ops.ir_se_unit(x, self)      # identity-shortcut unit: one block-level C call each way (xr_ir_block_fwd / bwd)
         link = ops.BnLink()
         b1, xs = rl[0].f_pass(x, link)
         sc = self._shortcut(xs)

@@ -23,7 +23,8 @@ _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_
         "res_trunk": int(_os.environ.get("XR_RES_TRUNK", "1")), "chain_units": int(_os.environ.get("XR_CHAIN_UNITS", "1")), "direct64_prelu": 1,
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0")), "f32_planes": 3,
         "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1")), "deterministic": 0,
-        "block_abi": int(_os.environ.get("XR_BLOCK_ABI", "1")), "conv1x1_subsample": int(_os.environ.get("XR_CONV1X1_SUBSAMPLE", "0")), "dgrad_s2": int(_os.environ.get("XR_DGRAD_S2", "0"))}
+        "block_abi": int(_os.environ.get("XR_BLOCK_ABI", "1")), "conv1x1_subsample": int(_os.environ.get("XR_CONV1X1_SUBSAMPLE", "0")), "dgrad_s2": int(_os.environ.get("XR_DGRAD_S2", "0")),
+        "ir_block": int(_os.environ.get("XR_IR_BLOCK", "1"))}
 
 
 if _os.environ.get("XR_DETERMINISTIC", "0") == "1":   # host half of the switch (see set_deterministic); _lib.load() sets the device half
@@ -1921,6 +1922,193 @@ def bn_se_add(y, bn, se, shortcut):
     tail = TailLink() if (training and _cfg["chain_units"] and torch.is_grad_enabled() and y.requires_grad) else None
     out = _BnSeAdd.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, se.fc1.weight, se.fc2.weight, shortcut, training,
                          mom, bn.eps, tail)
+    if tail is not None:
+        out._xr_tail = tail
+    return out
+
+
+# ------------------------------------------------------------------------------------------------- IR-SE unit, block level
+def _ir_block_fields():
+    P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    ints = ("wgrad_rows", "fold_in", "pg", "ep_spread", "da_spread", "split", "dw_accumulate", "dalpha_accumulate", "reserved")
+    ptrs = ("g1", "b1", "rmean1", "rvar1", "w1_fwd", "w2_fwd", "w1_dgrad", "w2_dgrad", "alpha", "g2", "b2", "rmean2", "rvar2", "se1", "se2",
+            "x", "bn1", "y1", "p1", "y2", "out", "stats_in", "pivot_in", "stats_own", "pivot_own", "mean1", "invstd1", "scale1", "shift1",
+            "sums2", "mean2", "invstd2", "a2", "b2c", "pooled", "hidden", "s", "cA", "cB", "stats_out", "pivot_out",
+            "dout", "tail_red", "red_tail", "dpre2", "dhid", "dp", "coef2", "dg2", "db2", "dy2", "dy1", "db1t", "dx", "dal_s", "dalpha",
+            "red1", "coef1", "dg1", "db1g", "prev_y2", "prev_red2", "slabs1", "slabs2", "dw1", "dw2", "dse1", "dse2", "side_stream",
+            "fork_event")
+    return ([(k, I) for k in ("N", "H", "W", "C", "Cr")] + [("eps", F), ("momentum", F)] + [(k, I) for k in ints] + [(k, P) for k in ptrs])
+
+
+class _IrBlockDesc(ctypes.Structure):
+    """include/xrface.h: xr_ir_block_desc (field for field; the size is checked against the library once)."""
+    _fields_ = _ir_block_fields()
+
+
+_ir_desc_checked = [False]
+
+
+def _ir_block_desc(**kw):
+    if not _ir_desc_checked[0]:
+        if lib.xr_ir_block_desc_size() != ctypes.sizeof(_IrBlockDesc):
+            raise RuntimeError("xrface: xr_ir_block_desc layout mismatch between include/xrface.h and xrface.ops")
+        _ir_desc_checked[0] = True
+    d = _IrBlockDesc()
+    for k, v in kw.items():
+        setattr(d, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+    return d
+
+
+class _IrSeUnit(Function):
+    """bottleneck_IR_SE with identity shortcut (model_irse.py:69-91) as ONE autograd node over the block-level entry points
+    xr_ir_block_fwd / xr_ir_block_bwd: the same launches, in the same order, as the op-level composition (BN1 with BnLink, conv ->
+    PReLU -> conv with the activation out of the epilogue, BatchNorm + SE + shortcut tail with TailLink), from one C call each way.
+    ``links``: (tail_prev, tail) -- the TailLink the previous unit attached to x (or None) and the one this unit offers."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, w1, alpha, w2, g2, b2, se1, se2, bn1, bn2, links):
+        x = _c(x)
+        N, H, W, C = x.shape
+        Cr = se1.shape[0]
+        HW = H * W
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        tail_prev, tail = links
+        pk1, _ = _packed(w1, "fwd", x.dtype, C, 1, 9, C, C, C * 9, 0, 1, 9)
+        pk2, _ = _packed(w2, "fwd", x.dtype, C, 1, 9, C, C, C * 9, 0, 1, 9)
+        fl = lambda t: _c(t.detach().float())
+        g1f, b1f, alf, g2f, b2f, se1f, se2f = fl(g1), fl(b1), fl(alpha), fl(g2), fl(b2), fl(se1), fl(se2)
+        pre = tail_prev.slink.take(x) if (tail_prev is not None and tail_prev.slink is not None) else None
+        pg = 0
+        sown = pown = None
+        if pre is None:     # no delivered statistics: BN1 takes its own over pseudo-groups, like _NormAct
+            pg = N if _cfg.get("deterministic") else max(d for d in range(1, min(N, 32) + 1) if N % d == 0)
+            sown, pown = zeros_f32((2, pg, C), dev), torch.empty((pg, C), **f32)
+        c8 = torch.empty((8, C), **f32)          # mean1 invstd1 scale1 shift1 mean2 invstd2 a2 b2c
+        nc4 = torch.empty((4, N, C), **f32)      # pooled s cA cB
+        hidden = torch.empty((N, Cr), **f32)
+        sums2 = zeros_f32((2, N, C), dev)
+        bn1t, y1, p1, y2, out = (torch.empty_like(x) for _ in range(5))
+        osum = opiv = None
+        if tail is not None:
+            osum, opiv = zeros_f32((2, N, C), dev), torch.empty((N, C), **f32)
+        d = _ir_block_desc(N=N, H=H, W=W, C=C, Cr=Cr, eps=bn1.eps, momentum=bn1.momentum, fold_in=0 if pre is None else pre[0].shape[1], pg=pg,
+                           g1=g1f, b1=b1f, rmean1=bn1.running_mean, rvar1=bn1.running_var, w1_fwd=pk1, w2_fwd=pk2, alpha=alf, g2=g2f, b2=b2f,
+                           rmean2=bn2.running_mean, rvar2=bn2.running_var, se1=se1f, se2=se2f, x=x, bn1=bn1t, y1=y1, p1=p1, y2=y2, out=out,
+                           stats_in=None if pre is None else pre[0], pivot_in=None if pre is None else pre[1], stats_own=sown,
+                           pivot_own=pown, mean1=c8[0], invstd1=c8[1], scale1=c8[2], shift1=c8[3], sums2=sums2, mean2=c8[4],
+                           invstd2=c8[5], a2=c8[6], b2c=c8[7], pooled=nc4[0], hidden=hidden, s=nc4[1], cA=nc4[2], cB=nc4[3],
+                           stats_out=osum, pivot_out=opiv)
+        lib.xr_ir_block_fwd(ctypes.addressof(d), stream())
+        if tail is not None:
+            tail.y = y2
+            tail.slink = StatsLink()
+            tail.slink.deliver(out, osum, opiv)
+        ctx.save_for_backward(x, bn1t, y1, p1, y2, c8, nc4, hidden, sums2, g1f, alf, g2f, se1f, se2f, w1, w2)
+        ctx.prefs = (g1, b1, w1, alpha, w2, g2, b2, se1, se2)
+        ctx.links = links
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, bn1t, y1, p1, y2, c8, nc4, hidden, sums2, g1f, alf, g2f, se1f, se2f, w1, w2 = ctx.saved_tensors
+        g1, b1, _w1, alpha, _w2, g2, b2, se1, se2 = ctx.prefs
+        tail_prev, tail = ctx.links
+        N, H, W, C = x.shape
+        Cr = hidden.shape[1]
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dout = _c(dout)
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        red_in = tail.take(dout) if tail is not None else None          # [2][N][C] from the next unit's BN1 backward
+        want = _wanted(w1)
+
+        def small(p_):
+            t_ = _direct(p_) if want else None
+            return t_, (t_ if t_ is not None else zeros_f32((C,), dev))
+        (t_g1, dg1), (t_b1, db1), (t_al, dal), (t_g2, dg2), (t_b2, db2) = small(g1), small(b1), small(alpha), small(g2), small(b2)
+        tw1, tw2 = (_direct(w1) if want else None), (_direct(w2) if want else None)
+        ts1, ts2 = (_direct(se1) if want else None), (_direct(se2) if want else None)
+        accum = tw1 is not None or tw2 is not None
+        fresh = torch.zeros_like if accum else torch.empty_like
+        dw1 = (tw1 if tw1 is not None else fresh(w1, dtype=torch.float32)) if want else None
+        dw2 = (tw2 if tw2 is not None else fresh(w2, dtype=torch.float32)) if want else None
+        dse1 = (ts1 if ts1 is not None else zeros_f32(tuple(se1.shape), dev)) if want else None
+        dse2 = (ts2 if ts2 is not None else zeros_f32(tuple(se2.shape), dev)) if want else None
+        all_direct = want and all(t is not None for t in (tw1, tw2, ts1, ts2))
+        side, side_h, ev_h = (None, None, None)
+        if all_direct and _cfg["wgrad_stream"] and not _graph["capturing"]:
+            if _side["stream"] is None or _side["dev"] != dev:
+                _side_fork(dev)
+            side, side_h, ev_h = _side["stream"], _side["stream"].cuda_stream, _side["ev"].cuda_event
+        kg = 9 * C
+        rows = bool(_cfg["wgrad_rows"] == 1 or (_cfg["wgrad_rows"] == 2 and C <= 128)) and 14 <= W <= 112
+        split = max(1, 256 // ((C // 64) * (C // 64))) if rows else _wgrad_split(N * H * W, C, kg)
+        slabs = torch.empty((2, split, C, kg), **f32) if want else None
+        da_sp = _cfg["dalpha_spread"] if N * H * W >= 32 * 1024 else 1
+        need_x = ctx.needs_input_grad[0]
+        chain = (tail_prev is not None and need_x and _cfg["chain_units"] and tail_prev.y is not None and tail_prev.y.shape == x.shape
+                 and tail_prev.y.dtype == x.dtype)
+        dy2, dy1, db1t = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        dx = torch.empty_like(x) if need_x else None
+        red2 = zeros_f32((2, N, C), dev) if chain else None
+        big = torch.empty((5, N, C), **f32)          # dpre2 dp coef2[3]
+        dhid = torch.empty((N, Cr), **f32)           # (read by the SE weight gradients on the side stream: must outlive this call)
+        d = _ir_block_desc(N=N, H=H, W=W, C=C, Cr=Cr, eps=0.0, momentum=0.0, wgrad_rows=int(rows), ep_spread=BnLink.SPREAD, da_spread=da_sp,
+                           split=split, dw_accumulate=int(accum), dalpha_accumulate=int(t_al is not None),
+                           g1=g1f, w1_dgrad=_packed(w1, "dgrad", x.dtype, C, 1, 9, C, C, 9, 0, 1, C * 9)[0],
+                           w2_dgrad=_packed(w2, "dgrad", x.dtype, C, 1, 9, C, C, 9, 0, 1, C * 9)[0], alpha=alf, g2=g2f,
+                           b1=g1f, b2=g2f,     # (the betas are not read by the backward pass: any non-null pointer)
+                           se1=se1f, se2=se2f, x=x, bn1=bn1t, y1=y1, p1=p1, y2=y2, mean1=c8[0], invstd1=c8[1], scale1=c8[2], shift1=c8[3],
+                           sums2=sums2, mean2=c8[4], invstd2=c8[5], a2=c8[6], b2c=c8[7], pooled=nc4[0], hidden=hidden, s=nc4[1], cA=nc4[2],
+                           cB=nc4[3], dout=dout, tail_red=red_in, red_tail=None if red_in is not None else zeros_f32((3, N, C), dev),
+                           dpre2=big[0], dhid=dhid, dp=big[1], coef2=big[2:], dg2=dg2, db2=db2, dy2=dy2, dy1=dy1,
+                           db1t=db1t, dx=dx, dal_s=zeros_f32((da_sp, C), dev), dalpha=dal, red1=zeros_f32((3, BnLink.SPREAD, C), dev),
+                           coef1=torch.empty((3, 1, C), **f32), dg1=dg1, db1g=db1, prev_y2=tail_prev.y if chain else None, prev_red2=red2,
+                           slabs1=slabs[0] if want else None, slabs2=slabs[1] if want else None, dw1=dw1, dw2=dw2, dse1=dse1, dse2=dse2,
+                           side_stream=side_h, fork_event=ev_h)
+        lib.xr_ir_block_bwd(ctypes.addressof(d), stream())
+        if side is not None:
+            _side_done(side, (x, bn1t, p1, dy2, dy1, slabs, nc4, hidden, big, dhid, c8, alf))
+        if chain:
+            tail_prev.deliver(dx, red2)
+        outs = []
+        for p_, t_, v in ((g1, t_g1, dg1), (b1, t_b1, db1), (w1, tw1, dw1), (alpha, t_al, dal), (w2, tw2, dw2), (g2, t_g2, dg2),
+                          (b2, t_b2, db2), (se1, ts1, dse1), (se2, ts2, dse2)):
+            if t_ is not None:
+                _direct_done(p_)
+                outs.append(None)
+            else:
+                outs.append(v if want else None)
+        return (dx, *outs, None, None, None)
+
+
+def ir_se_unit_ok(x, unit):
+    """The block-level path covers the training-mode identity-shortcut bottleneck_IR_SE units on bf16 tensors with C >= 128."""
+    if not (_cfg["ir_block"] and x.dtype == torch.bfloat16 and x.dim() == 4 and not _cfg.get("probe") and not _cfg.get("deterministic")
+            and torch.is_grad_enabled()):
+        return False
+    rl = unit.res_layer
+    C = x.shape[3]
+    if not (unit.training and C >= 128 and C % 64 == 0 and tuple(rl[1].weight.shape) == (C, C, 3, 3) and tuple(rl[3].weight.shape) == (C, C, 3, 3)
+            and rl[3].stride[0] == 1 and rl[0].track_running_stats and rl[4].track_running_stats and rl[0].momentum is not None
+            and rl[4].momentum is not None and x.numel() * 2 < (1 << 31)):
+        return False
+    if rl[0].momentum != rl[4].momentum or rl[0].eps != rl[4].eps:
+        return False
+    return all(p.requires_grad for p in unit.parameters()) and x.shape[2] >= 7
+
+
+def ir_se_unit(x, unit):
+    """bottleneck_IR_SE.f for the units ir_se_unit_ok accepts (identity shortcut: MaxPool2d(1, 1))."""
+    rl = unit.res_layer
+    rl[0]._count()
+    rl[4]._count()
+    tail_prev = chain_of(x)
+    tail = TailLink() if (_cfg["chain_units"] and x.requires_grad) else None
+    out = _IrSeUnit.apply(x, rl[0].weight, rl[0].bias, rl[1].weight, rl[2].weight, rl[3].weight, rl[4].weight, rl[4].bias, rl[5].fc1.weight,
+                          rl[5].fc2.weight, rl[0], rl[4], (tail_prev, tail))
     if tail is not None:
         out._xr_tail = tail
     return out

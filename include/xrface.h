@@ -275,6 +275,100 @@ int xr_resblock_desc_size(void);
 int xr_resblock_fwd(const xr_resblock_desc* d, void* stream);
 int xr_resblock_bwd(const xr_resblock_desc* d, void* stream);
 
+/* One bottleneck_IR_SE unit with identity shortcut (model_irse.py:69-91; in_channel == depth = C >= 64, C % 64 == 0, stride 1: 18 of the
+ * 24 units of IR-SE-50), bf16 NHWC tensors [N][H][W][C], training mode -- SURVEY 8b "xr_ir_block_{fwd,bwd}".
+ *   fwd: BN1 coefficients from partial statistics (stats_in [2][fold_in][C] + pivot_in [fold_in][C] delivered by the previous unit's
+ *        tail pass, or fold_in = 0: taken here over pg pseudo-groups into stats_own / pivot_own) incl. the running-statistics update ->
+ *        bn1 = BN1(x) -> y1 = conv3x3(bn1) with p1 = prelu(y1, alpha) as second output -> y2 = conv3x3(p1) -> per-image sums of y2 ->
+ *        BN2 coefficients (a2, b2c; running statistics) -> SE squeeze / excite (pooled, hidden, s, cA, cB) -> out = y2 * cA + cB + x,
+ *        with the per-image statistics of out for the next unit's BN1 (stats_out [2][N][C] zeroed + pivot_out [N][C]; NULL: skipped).
+ *   bwd: tail (S1 / S2 per image delivered in tail_red [2][N][C] by the next unit's BN1 backward, or one reduce pass into red_tail
+ *        [3][N][C] zeroed) -> xr_bnse_bwd -> dy2 -> SE weight gradients -> conv2 input gradient with the PReLU backward in its epilogue
+ *        (dal_s [da_spread][C] zeroed, folded into dalpha) -> conv1 input gradient with BN1's backward sums in its epilogue (red1
+ *        [3][ep_spread][C] zeroed) -> BN1 coefficients -> dx = BN1-backward(db1t) + dout; with prev_y2 the same pass takes the previous
+ *        tail's sums (prev_red2 [2][N][C] zeroed).  Weight gradients (wgrad_rows != 0: xr_conv_wgrad_rows, else xr_conv_wgrad; `split`
+ *        slabs of [C][9 C] floats each in slabs1 / slabs2) and the SE ones run on side_stream after fork_event when given.
+ * dg / db / dalpha / dse targets are accumulated (+=; dalpha by dalpha_accumulate); NULL targets are skipped. */
+typedef struct xr_ir_block_desc {
+  int N, H, W, C, Cr;
+  float eps, momentum;
+  int wgrad_rows, fold_in, pg, ep_spread, da_spread, split, dw_accumulate, dalpha_accumulate, reserved;
+  const float* g1;         /* BN1 gamma / beta [C], running statistics (updated) */
+  const float* b1;
+  float* rmean1;
+  float* rvar1;
+  const void* w1_fwd;      /* [C][9 C] bf16 packs */
+  const void* w2_fwd;
+  const void* w1_dgrad;
+  const void* w2_dgrad;
+  const float* alpha;      /* PReLU slope [C] */
+  const float* g2;         /* BN2 */
+  const float* b2;
+  float* rmean2;
+  float* rvar2;
+  const float* se1;        /* SE fc1 [Cr][C], fc2 [C][Cr] fp32 */
+  const float* se2;
+  const void* x;           /* unit input = shortcut */
+  void* bn1;               /* BN1(x) (saved: conv1's weight gradient) */
+  void* y1;
+  void* p1;
+  void* y2;
+  void* out;
+  const float* stats_in;
+  const float* pivot_in;
+  float* stats_own;        /* [2][pg][C] zeroed + [pg][C] */
+  float* pivot_own;
+  float* mean1;            /* [C] each */
+  float* invstd1;
+  float* scale1;
+  float* shift1;
+  float* sums2;            /* [2][N][C] zeroed */
+  float* mean2;            /* [C] each */
+  float* invstd2;
+  float* a2;
+  float* b2c;
+  float* pooled;           /* [N][C] */
+  float* hidden;           /* [N][Cr] */
+  float* s;                /* [N][C] */
+  float* cA;
+  float* cB;
+  float* stats_out;
+  float* pivot_out;
+  /* ---- backward only */
+  const void* dout;
+  const float* tail_red;
+  float* red_tail;
+  float* dpre2;            /* [N][C] */
+  float* dhid;             /* [N][Cr] */
+  float* dp;               /* [N][C] */
+  float* coef2;            /* [3][N][C] */
+  float* dg2;
+  float* db2;
+  void* dy2;               /* workspace tensors laid out like x */
+  void* dy1;
+  void* db1t;
+  void* dx;                /* NULL: no input gradient */
+  float* dal_s;
+  float* dalpha;
+  float* red1;
+  float* coef1;            /* [3][C] */
+  float* dg1;
+  float* db1g;
+  const void* prev_y2;
+  float* prev_red2;
+  float* slabs1;
+  float* slabs2;
+  float* dw1;              /* [C][C][3][3] parameter-layout targets (NULL: skipped) */
+  float* dw2;
+  float* dse1;             /* [Cr][C] / [C][Cr] (both or none) */
+  float* dse2;
+  void* side_stream;
+  void* fork_event;
+} xr_ir_block_desc;
+int xr_ir_block_desc_size(void);
+int xr_ir_block_fwd(const xr_ir_block_desc* d, void* stream);
+int xr_ir_block_bwd(const xr_ir_block_desc* d, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Normalisation / activation family.  Tensors are [G][rows][C] (G groups of `rows` pixels):
  * BatchNorm2d/1d: G = 1, rows = N*H*W (model_irse.py:56-60,141,144,148; model/resnet.py:24,27,159,167,173);

@@ -785,6 +785,7 @@ def test_bn_backward_reduction_fused_into_conv_dgrad(cin, depth, stride, hw, dty
             taken.append(r is not None)
             return r
         ops.BnLink.take = spy
+        ops._cfg["ir_block"] = 0     # the op-level composition is under test here (the block-level path has its own test)
         for mode in (0, 1):
             ops._cfg["fuse_bn_reduce"] = mode
             blk = copy.deepcopy(blk0)
@@ -803,6 +804,7 @@ def test_bn_backward_reduction_fused_into_conv_dgrad(cin, depth, stride, hw, dty
     finally:
         ops.BnLink.take = orig_take
         ops._cfg["fuse_bn_reduce"] = 1
+        ops._cfg["ir_block"] = 1
         xrface.set_compute_dtype(torch.float32)
 
 
@@ -948,6 +950,59 @@ def test_fused_statistics_and_second_reduction_kernels(n, hw, c, dtype):
     dd, wd = dx_ref.double(), y2.double()
     for got, want, mag in ((red2[0], dd.sum(1), dd.abs().sum(1)), (red2[1], (dd * wd).sum(1), (dd * wd).abs().sum(1))):
         assert float(((got.double() - want).abs() / mag).max()) < 2e-6
+
+
+@pytest.mark.parametrize("c,hw,n", [(128, 28, 6), (256, 14, 32), (512, 7, 16)])
+def test_ir_se_unit_block_level_path_equals_op_level_path(c, hw, n):
+    """xr_ir_block_fwd / xr_ir_block_bwd (one C call per identity-shortcut bottleneck_IR_SE unit each way, ops._IrSeUnit) against the
+    op-level composition it replaces (BN1 + BnLink, conv -> PReLU -> conv, BatchNorm + SE tail + TailLink): three chained units in
+    bf16, forward output, input gradient, every parameter gradient and the BatchNorm running statistics -- the same kernels in the
+    same order, so the two agree to the run-to-run spread of the fp32 atomics; the block path must really have been taken, and
+    the links between block-level and op-level units (statistics forward, tail sums backward) must work in both directions."""
+    import copy
+    import xrface
+    from xrface import ops
+    from xrface.model.model_irse import bottleneck_IR_SE
+    xrface.set_compute_dtype(torch.bfloat16)
+    calls = {"fwd": 0}
+    orig = ops._IrSeUnit.forward
+
+    def spy(ctx, *a):
+        calls["fwd"] += 1
+        return orig(ctx, *a)
+    try:
+        ops._IrSeUnit.forward = staticmethod(spy)
+        torch.manual_seed(21)
+        units0 = torch.nn.ModuleList([bottleneck_IR_SE(c, c, 1) for _ in range(3)]).to(DEV).train()
+        x0 = rnd(f"irb{c}", n, c, hw, hw)
+        res = {}
+        # modes: block-level everywhere / op-level everywhere (twice: the yardstick) / mixed (unit 1 op-level between two block-level units)
+        for mode in ("block", "ops", "ops2", "mixed"):
+            units = copy.deepcopy(units0)
+            x = x0.to(DEV).requires_grad_(True)
+            y = ops.enter(x, torch.bfloat16)
+            for i, u in enumerate(units):
+                ops._cfg["ir_block"] = int(mode == "block" or (mode == "mixed" and i != 1))
+                y = u.f(y)
+            out = ops.leave(y)
+            out.float().square().mean().backward()
+            torch.cuda.synchronize()
+            stats = [b.clone() for nme, b in units.named_buffers() if "running" in nme]
+            res[mode] = [out.detach().float().cpu(), x.grad.cpu()] + [p.grad.float().cpu() for p in units.parameters()] + [t.cpu() for t in stats]
+        assert calls["fwd"] == 3 + 2, calls
+        # yardstick: two runs of the op-level path differ by the order of the fp32 atomics (times bf16 re-rounding)
+        spread = [rel(a, b) for a, b in zip(res["ops2"], res["ops"])]
+        for other in ("block", "mixed"):
+            for i, (a, b) in enumerate(zip(res[other], res["ops"])):
+                assert rel(a, b) < max(4e-2, 3.0 * spread[i]), (other, i, rel(a, b), spread[i])
+        # forward outputs and running statistics do not depend on atomics order beyond fp32 rounding
+        assert rel(res["block"][0], res["ops"][0]) < 1e-2
+        for a, b in zip(res["block"][-12:], res["ops"][-12:]):
+            assert rel(a, b) < 3e-3     # (statistics of bf16 tensors that already differ in their last bits)
+    finally:
+        ops._IrSeUnit.forward = orig
+        ops._cfg["ir_block"] = 1
+        xrface.set_compute_dtype(torch.float32)
 
 
 def test_input_layer_offers_statistics_to_the_first_unit():
