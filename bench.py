@@ -155,9 +155,10 @@ def isolated_ms(tag, batch, dev, reps=8):
 
 def pmc_traffic(kernel, site):
     """HBM bytes per launch of the dominant kernel from this round's committed rocprofv3 PMC passes
-    (profiles/r02_counters.json, written by tools/pmc_kernels.sh at the current HEAD); None when that site was not profiled."""
+    (profiles/r03_counters.json, written by tools/pmc_kernels.sh + tools/pmc_to_json.py with the convolution kernels of the current
+    HEAD); None when that site was not profiled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_counters.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_counters.json")) as f:
             db = json.load(f)
         return db["sites"][site]["hbm_bytes_per_launch"]
     except Exception:
