@@ -285,6 +285,9 @@ struct AffP {
   // sum dx * y2 over the rows of group g; with bcast the coefficients are per channel and shared by all groups
   const void* y2; float* red2; int bcast;
   float* pivot;        // xr_affine_act_stats_pivot: [G][C], the statistics are taken relative to it (and it is written)
+  // xr_affine_act_bwd_apply_sub: dx_add is COMPACT, [N][H / s][W / s][C] -- the gradient of a sub-sampled identity branch
+  // (MaxPool2d(1, s), model_irse.py:53); it is added at the pixels with h % s == 0 and w % s == 0 only.  0 = dense dx_add.
+  int sub_s, sub_H, sub_W;
 };
 
 template <typename T> __device__ __forceinline__ float as_stored(float v);   // the value a later pass reads back
@@ -550,7 +553,18 @@ __global__ __launch_bounds__(NT) void affine_act_bwd_apply_kernel(AffP p, Geo ge
       ld8(x + (size_t)r * geo.C, v);
       ld8(dy + (size_t)r * geo.C, d);
       if (res) ld8(res + (size_t)r * geo.C, rv);
-      if (dxa) ld8(dxa + (size_t)r * geo.C, ex);
+      bool addx = dxa != nullptr;
+      if (addx) {
+        if (p.sub_s > 0) {      // compact strided add: pixel (n, h, w) of the full grid takes dx_add[n][h / s][w / s] when both divide
+          const int pix = g * geo.rows + r;
+          const int wq = pix % p.sub_W, hn = pix / p.sub_W, hq = hn % p.sub_H, n = hn / p.sub_H;
+          addx = (hq % p.sub_s == 0) && (wq % p.sub_s == 0);
+          if (addx)
+            ld8(reinterpret_cast<const T*>(p.dx_add) + ((size_t)(n * (p.sub_H / p.sub_s) + hq / p.sub_s) * (p.sub_W / p.sub_s) + wq / p.sub_s) * geo.C + cch * 8, ex);
+        } else {
+          ld8(dxa + (size_t)r * geo.C, ex);
+        }
+      }
       if constexpr (RED2) ld8(y2 + (size_t)r * geo.C, w);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(NT) void affine_act_bwd_apply_kernel(AffP p, Geo ge
         const float dz = d[e] * act_grad(z, al[e], p.act);
         dzv[e] = dz;
         o[e] = cA[e] * dz + cB[e] * v[e] + cC[e];
-        if (dxa) o[e] += ex[e];
+        if (addx) o[e] += ex[e];
         if constexpr (RED2) {
           const float q = as_stored<T>(o[e]);
           acc[0][e] += q;
@@ -1012,6 +1026,31 @@ extern "C" int xr_affine_act_bwd_apply(int dtype, const void* x, const float* sc
   if (dtype == XR_BF16)
     return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t, false>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
   return launch_aff<float>(affine_act_bwd_apply_kernel<float, false>, p, geo, 0, (hipStream_t)stream, "xr_affine_act_bwd_apply");
+}
+
+extern "C" int xr_affine_act_bwd_apply_sub(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                           const float* alpha, int act, const void* dy, const float* coef, void* dx, int N, int H, int W,
+                                           int C, const void* dx_add_sub, int sub_stride, const void* y2, float* red2, void* stream) {
+  if (int e = check_geo("xr_affine_act_bwd_apply_sub", dtype, N, H * W, C)) return e;
+  XR_CHECK_ARG(x && dy && dx && dx_add_sub, "xr_affine_act_bwd_apply_sub: null pointer");
+  XR_CHECK_ARG(N > 0 && H > 0 && W > 0 && sub_stride >= 2 && H % sub_stride == 0 && W % sub_stride == 0,
+               "xr_affine_act_bwd_apply_sub: H and W must be multiples of the stride");
+  XR_CHECK_ARG((y2 == nullptr) == (red2 == nullptr), "xr_affine_act_bwd_apply_sub: y2 and red2 come together");
+  XR_CHECK_ARG(act != XR_ACT_PRELU || alpha, "xr_affine_act_bwd_apply_sub: PReLU needs alpha");
+  hipStream_t st = (hipStream_t)stream;
+  if (red2 != nullptr) {   // chained with the previous unit's tail: one group per image, shared coefficients (xr_affine_act_bwd_apply_red)
+    AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, nullptr, 1, dx_add_sub, y2, red2, 1};
+    p.sub_s = sub_stride; p.sub_H = H; p.sub_W = W;
+    Geo geo = make_geo(N, H * W, C, 2 * g_tune[9], true);
+    const size_t smem = (size_t)(geo.rpb > 8 ? geo.rpb : 8) * C * sizeof(float);
+    if (dtype == XR_BF16) return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t, true>, p, geo, smem, st, "xr_affine_act_bwd_apply_sub");
+    return launch_aff<float>(affine_act_bwd_apply_kernel<float, true>, p, geo, smem, st, "xr_affine_act_bwd_apply_sub");
+  }
+  AffP p{x, scale, shift, res, alpha, act, nullptr, dy, nullptr, coef, dx, nullptr, 1, dx_add_sub};
+  p.sub_s = sub_stride; p.sub_H = H; p.sub_W = W;
+  Geo geo = make_geo(1, N * H * W, C, 4096);
+  if (dtype == XR_BF16) return launch_aff<bf16_t>(affine_act_bwd_apply_kernel<bf16_t, false>, p, geo, 0, st, "xr_affine_act_bwd_apply_sub");
+  return launch_aff<float>(affine_act_bwd_apply_kernel<float, false>, p, geo, 0, st, "xr_affine_act_bwd_apply_sub");
 }
 
 extern "C" int xr_affine_act_bwd_apply_red(int dtype, const void* x, const float* scale, const float* shift, const void* res,

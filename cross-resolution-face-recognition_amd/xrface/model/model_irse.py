@@ -70,17 +70,33 @@ class bottleneck_IR(Module):
         y1, p1 = ops.conv2d_prelu(b1, c1.weight, rl[2].weight, c1.bias, c1.stride[0], c1.padding[0], link)  # PReLU out of the epilogue
         return ops.prelu_conv2d(y1, rl[2].weight, c2.weight, c2.stride[0], c2.padding[0], p1)
 
-    def _shortcut(self, x):
+    def _shortcut(self, x, presub=False):
+        """presub: x already is the block input sub-sampled by the unit's stride (second output of the opening BatchNorm)."""
         if isinstance(self.shortcut_layer, Sequential):
+            if presub:   # 1x1 / stride s on the full input == 1x1 / stride 1 on the sub-sampled input
+                conv, bn = self.shortcut_layer[0], self.shortcut_layer[1]
+                link = ops.StatsLink() if (bn.training or not bn.track_running_stats) else None
+                return bn.f(ops.conv2d(x, conv.weight, conv.bias, 1, 0, link), slink=link)
             return xnn.conv_bn(self.shortcut_layer[0], self.shortcut_layer[1], x)   # BN statistics out of the conv epilogue
-        return self.shortcut_layer.f(x)
+        return x if presub else self.shortcut_layer.f(x)
+
+    def _sub_stride(self, x):
+        """Stride by which the opening BatchNorm may hand the shortcut a sub-sampled input (0: it hands the input itself)."""
+        sl = self.shortcut_layer
+        s_ = sl[0].stride[0] if isinstance(sl, Sequential) else (sl.stride if isinstance(sl.stride, int) else sl.stride[0])
+        if isinstance(sl, Sequential) and (sl[0].kernel_size != (1, 1) or sl[0].padding != (0, 0)):
+            return 0
+        ok = (ops._cfg["sub_pass"] and s_ >= 2 and x.shape[1] % s_ == 0 and x.shape[2] % s_ == 0 and self.training
+              and torch.is_grad_enabled() and x.requires_grad)
+        return s_ if ok else 0
 
     def f(self, x):
         # the block input feeds both the BN of the residual branch and the shortcut: route the shortcut through the
         # BN op's pass-through output so the two input gradients are summed inside its backward kernel
         link = ops.BnLink()
-        b1, xs = self.res_layer[0].f_pass(x, link)
-        sc = self._shortcut(xs)
+        sub = self._sub_stride(x)
+        b1, xs = self.res_layer[0].f_pass(x, link, sub or 1)
+        sc = self._shortcut(xs, presub=bool(sub))
         r = self._conv_prelu_conv(b1, link)
         return self.res_layer[4].f(r, res=sc)
 
@@ -104,8 +120,9 @@ class bottleneck_IR_SE(bottleneck_IR):
         if not isinstance(self.shortcut_layer, Sequential) and ops.ir_se_unit_ok(x, self) and self.shortcut_layer.stride in (1, (1, 1)):
             return ops.ir_se_unit(x, self)      # identity-shortcut unit: one block-level C call each way (xr_ir_block_fwd / bwd)
         link = ops.BnLink()
-        b1, xs = rl[0].f_pass(x, link)
-        sc = self._shortcut(xs)
+        sub = self._sub_stride(x)
+        b1, xs = rl[0].f_pass(x, link, sub or 1)
+        sc = self._shortcut(xs, presub=bool(sub))
         y2 = self._conv_prelu_conv(b1, link)
         return ops.bn_se_add(y2, rl[4], rl[5], sc)   # BatchNorm + SE + shortcut add in one elementwise pass
 

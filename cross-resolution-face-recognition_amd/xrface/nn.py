@@ -149,14 +149,15 @@ class _BNMixin:
 
 
 
-    def f_pass(self, buf, link=None):
+    def f_pass(self, buf, link=None, sub=1):
         """(bn(buf), buf'): buf' aliases buf and carries the identity-branch gradient into this norm's backward.
-        link: an ops.BnLink shared with the one convolution that consumes bn(buf) (fused backward reduction)."""
+        link: an ops.BnLink shared with the one convolution that consumes bn(buf) (fused backward reduction).
+        sub >= 2: buf' is buf sub-sampled by that stride (its gradient then comes back compact)."""
         training = self.training or not self.track_running_stats
         self._count()
         mom = self._momentum()
         return ops.norm_act_pass(buf, self.weight, self.bias, self.running_mean, self.running_var, "bn", None, training, mom,
-                                 self.eps, link if training else None, ops.chain_of(buf))
+                                 self.eps, link if training else None, ops.chain_of(buf), sub)
 
 
 class BatchNorm2d(_BNMixin, nn.BatchNorm2d):

@@ -24,7 +24,7 @@ _cfg = {"compute_dtype": torch.float32, "wgrad_blocks": int(_os.environ.get("XR_
         "wgrad_rows112": int(_os.environ.get("XR_WGRAD_ROWS112", "0")), "f32_planes": 3,
         "wgrad64_stream": int(_os.environ.get("XR_WGRAD64_STREAM", "1")), "deterministic": 0,
         "block_abi": int(_os.environ.get("XR_BLOCK_ABI", "1")), "conv1x1_subsample": int(_os.environ.get("XR_CONV1X1_SUBSAMPLE", "0")), "dgrad_s2": int(_os.environ.get("XR_DGRAD_S2", "0")),
-        "ir_block": int(_os.environ.get("XR_IR_BLOCK", "1"))}
+        "ir_block": int(_os.environ.get("XR_IR_BLOCK", "1")), "sub_pass": int(_os.environ.get("XR_SUB_PASS", "1"))}
 
 
 if _os.environ.get("XR_DETERMINISTIC", "0") == "1":   # host half of the switch (see set_deterministic); _lib.load() sets the device half
@@ -1123,8 +1123,13 @@ class _NormAct(Function):
         ctx.meta = (mode, a, stats, G, rows, C, eps, gamma is not None, beta is not None, alpha is not None)
         ctx.prefs = (gamma, beta, alpha)
         ctx.per_img = (per_img, pg, (N // pg) * H * W)
-        if passthrough:  # second output aliases the input: its gradient is folded into dx by the apply kernel
+        if passthrough is True:  # second output aliases the input: its gradient is folded into dx by the apply kernel
             return y, x.view_as(x)
+        if passthrough:          # stride s >= 2: second output = the sub-sampled input (MaxPool2d(1, s), model_irse.py:53); its
+            s_ = int(passthrough)   # COMPACT gradient is added at the strided pixels by the apply kernel (xr_affine_act_bwd_apply_sub)
+            xs = torch.empty((N, (H + s_ - 1) // s_, (W + s_ - 1) // s_, C), dtype=x.dtype, device=dev)
+            lib.xr_subsample(dt(x), ptr(x), ptr(xs), N, H, W, C, s_, stream())
+            return y, xs
         return y
 
     @staticmethod
@@ -1199,10 +1204,22 @@ class _NormAct(Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dres = torch.empty_like(x) if (res is not None and ctx.needs_input_grad[5]) else None
         tail = ctx.tail
-        if (tail is not None and dx is not None and dres is None and mode == "bn" and G == 1 and _cfg["chain_units"]
-                and tail.y is not None and tail.y.shape == x.shape and tail.y.dtype == x.dtype):
+        sub = ctx.passthrough if (ctx.passthrough is not True and ctx.passthrough) else 0
+        chain = (tail is not None and dx is not None and dres is None and mode == "bn" and G == 1 and _cfg["chain_units"]
+                 and tail.y is not None and tail.y.shape == x.shape and tail.y.dtype == x.dtype)
+        if sub and dpass is not None and dx is not None:
+            # the identity branch was sub-sampled: its compact gradient goes in at the strided pixels (no zero-filled full-size tensor)
+            n_img, h_, w_ = x.shape[0], x.shape[1], x.shape[2]
+            red2 = zeros_f32((2, n_img, C), x.device) if chain else None
+            lib.xr_affine_act_bwd_apply_sub(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx), n_img,
+                                            h_, w_, C, ptr(dpass), int(sub), ptr(tail.y) if chain else None, ptr(red2), stream())
+            if chain:
+                tail.deliver(dx, red2)
+            return dx, dgamma, dbeta, None, None, dres, dalpha, None, None, None, None, None, None, None, None, None, None, None
+        if chain:
             # dx IS the gradient entering the tail of the unit before this norm: take that tail's per-image sums here
             n_img = x.shape[0]
+            assert not sub or dpass is None
             red2 = zeros_f32((2, n_img, C), x.device)
             lib.xr_affine_act_bwd_apply_red(dt(x), ptr(x), ptr(scale), ptr(shift), ptr(res), ptr(al), a, ptr(dy), ptr(coef), ptr(dx),
                                             None, n_img, rows // n_img, C, ptr(dpass), ptr(tail.y), ptr(red2), stream())
@@ -1268,11 +1285,13 @@ def chain_of(x):
 
 
 def norm_act_pass(x, gamma=None, beta=None, rmean=None, rvar=None, mode="bn", act=None, training=True, momentum=0.1, eps=EPS,
-                  link=None, tail=None):
+                  link=None, tail=None, sub=1):
     """(norm(x), x'): x' aliases x; route identity branches (block shortcuts) through x' and the two gradients of x are
-    summed inside the norm's backward apply kernel instead of by a separate elementwise pass."""
+    summed inside the norm's backward apply kernel instead of by a separate elementwise pass.  sub = s >= 2: x' is x sub-sampled
+    by s (the MaxPool2d(1, s) shortcut / the input of a 1x1 stride-s shortcut convolution) and comes back as a compact gradient."""
     slink = tail.slink if tail is not None else None
-    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, True, link, slink, None,
+    pt = True if sub <= 1 else int(sub)
+    return _NormAct.apply(x, gamma, beta, rmean, rvar, None, None, mode, act, training, momentum, eps, pt, link, slink, None,
                           tail if training else None)
 
 

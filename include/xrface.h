@@ -442,6 +442,15 @@ int xr_affine_act_bwd_apply(int dtype, const void* x, const float* scale, const 
 /* dx_add (optional, laid out like x): added to dx -- the gradient arriving through an identity branch of the same
  * input (block shortcut), so autograd's separate summation pass disappears. */
 
+/* The same pass for a BatchNorm (G = 1 over [N][H][W][C]) whose input ALSO feeds a strided identity branch (MaxPool2d(1, s) shortcut of a
+ * stage-opening unit, model_irse.py:53,62-66; or the sub-sampled input of its 1x1 shortcut convolution): dx_add_sub is that branch's
+ * gradient in COMPACT form [N][H / s][W / s][C] and is added at the pixels with h % s == 0 and w % s == 0 -- the zero-filled full-size
+ * tensor of xr_subsample_bwd (written once, read once) never exists. */
+int xr_affine_act_bwd_apply_sub(int dtype, const void* x, const float* scale, const float* shift, const void* res,
+                                const float* alpha, int act, const void* dy, const float* coef, void* dx, int N, int H, int W,
+                                int C, const void* dx_add_sub, int sub_stride, const void* y2, float* red2, void* stream);
+/* y2 / red2 != NULL: also the second reduction of xr_affine_act_bwd_apply_red (one group per image). */
+
 /* Pass 2 of a BatchNorm that OPENS a residual unit, chained with pass 1 of the unit before it (model_irse.py:76-91): the G
  * groups are the images (rows = H*W), scale / shift / coef are per channel ([C], [3][C]: one statistics group spanning the
  * batch), and while dx -- which is the gradient dout entering the previous unit's tail out = SE(BN(y2)) + shortcut -- streams

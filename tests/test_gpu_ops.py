@@ -956,14 +956,15 @@ def test_fused_statistics_and_second_reduction_kernels(n, hw, c, dtype):
 def test_ir_se_unit_block_level_path_equals_op_level_path(c, hw, n):
     """xr_ir_block_fwd / xr_ir_block_bwd (one C call per identity-shortcut bottleneck_IR_SE unit each way, ops._IrSeUnit) against the
     op-level composition it replaces (BN1 + BnLink, conv -> PReLU -> conv, BatchNorm + SE tail + TailLink): three chained units in
-    bf16, forward output, input gradient, every parameter gradient and the BatchNorm running statistics -- the same kernels in the
-    same order, so the two agree to the run-to-run spread of the fp32 atomics; the block path must really have been taken, and
-    the links between block-level and op-level units (statistics forward, tail sums backward) must work in both directions."""
+    bf16 -- forward output, input gradient, every parameter gradient and the BatchNorm running statistics.  Same kernels in the same
+    order, so the two differ only by the order of the fp32 atomics (times bf16 re-rounding); the yardstick is the fp32 parity mode
+    on the same weights: the block-level path must sit as close to it as the op-level path does (some of these gradients -- the SE
+    fc1 weight -- are ill-conditioned in bf16: 10-25 % off the fp32 value on EITHER path).  The block path must really have been
+    taken, and the links between block-level and op-level units (statistics forward, tail sums backward) must work both ways."""
     import copy
     import xrface
     from xrface import ops
     from xrface.model.model_irse import bottleneck_IR_SE
-    xrface.set_compute_dtype(torch.bfloat16)
     calls = {"fwd": 0}
     orig = ops._IrSeUnit.forward
 
@@ -976,11 +977,12 @@ def test_ir_se_unit_block_level_path_equals_op_level_path(c, hw, n):
         units0 = torch.nn.ModuleList([bottleneck_IR_SE(c, c, 1) for _ in range(3)]).to(DEV).train()
         x0 = rnd(f"irb{c}", n, c, hw, hw)
         res = {}
-        # modes: block-level everywhere / op-level everywhere (twice: the yardstick) / mixed (unit 1 op-level between two block-level units)
-        for mode in ("block", "ops", "ops2", "mixed"):
+        # modes: fp32 parity mode (op-level: the reference) / bf16 op-level / bf16 block-level / bf16 mixed (unit 1 op-level)
+        for mode, dtype in (("f32", torch.float32), ("ops", torch.bfloat16), ("block", torch.bfloat16), ("mixed", torch.bfloat16)):
+            xrface.set_compute_dtype(dtype)
             units = copy.deepcopy(units0)
             x = x0.to(DEV).requires_grad_(True)
-            y = ops.enter(x, torch.bfloat16)
+            y = ops.enter(x, dtype)
             for i, u in enumerate(units):
                 ops._cfg["ir_block"] = int(mode == "block" or (mode == "mixed" and i != 1))
                 y = u.f(y)
@@ -990,12 +992,11 @@ def test_ir_se_unit_block_level_path_equals_op_level_path(c, hw, n):
             stats = [b.clone() for nme, b in units.named_buffers() if "running" in nme]
             res[mode] = [out.detach().float().cpu(), x.grad.cpu()] + [p.grad.float().cpu() for p in units.parameters()] + [t.cpu() for t in stats]
         assert calls["fwd"] == 3 + 2, calls
-        # yardstick: two runs of the op-level path differ by the order of the fp32 atomics (times bf16 re-rounding)
-        spread = [rel(a, b) for a, b in zip(res["ops2"], res["ops"])]
         for other in ("block", "mixed"):
-            for i, (a, b) in enumerate(zip(res[other], res["ops"])):
-                assert rel(a, b) < max(4e-2, 3.0 * spread[i]), (other, i, rel(a, b), spread[i])
-        # forward outputs and running statistics do not depend on atomics order beyond fp32 rounding
+            for i, (a, o, r) in enumerate(zip(res[other], res["ops"], res["f32"])):
+                e_blk, e_ops = rel(a, r), rel(o, r)
+                assert e_blk < max(5e-2, 2.5 * e_ops), (other, i, e_blk, e_ops)   # (two samples of a noisy quantity each)
+        # forward outputs and running statistics do not depend on the atomics' order beyond rounding
         assert rel(res["block"][0], res["ops"][0]) < 1e-2
         for a, b in zip(res["block"][-12:], res["ops"][-12:]):
             assert rel(a, b) < 3e-3     # (statistics of bf16 tensors that already differ in their last bits)
