@@ -50,8 +50,16 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved
   return __builtin_bit_cast(unsigned short, b);
 }
-// pack two floats -> two bf16 in one dword (lo = a, hi = b)
-__device__ __forceinline__ unsigned pack2bf(float a, float b) { return (unsigned)f2bf(a) | ((unsigned)f2bf(b) << 16); }
+// pack two floats -> two bf16 in one dword (lo = a, hi = b): ONE v_cvt_pk_bf16_f32 (the element-wise form costs two conversions
+// plus three bit operations -- a fifth of the VALU work of the fused direct-convolution epilogues, which are issue-bound)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ unsigned pack2bf(f32x2_t v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t)); }
+// the two bf16 of a dword as floats (lo, hi)
+__device__ __forceinline__ f32x2_t unpack2bf(unsigned w) { return (f32x2_t){__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)}; }
 
 // split fp32 into hi + lo bf16 (x ~= hi + lo, |err| <~ 2^-17 |x|)
 __device__ __forceinline__ void split_bf(float x, bf16_t& hi, bf16_t& lo) {

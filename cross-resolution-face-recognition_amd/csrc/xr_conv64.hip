@@ -5,8 +5,9 @@
 // Why not the implicit GEMM of xr_conv.hip: with C = K = 64 a K-loop has only nine stages, the im2col gather re-reads the
 // input nine times through the texture path and the 128x64 tiles are instruction-issue bound (~13 VALU per MFMA).  Here
 //   * the 64 x 576 weight panel lives in REGISTERS as MFMA A-operand fragments for the whole kernel: persistent workgroups
-//     (one per CU, 8 waves = two per SIMD), wave = (32-channel half, 2 of the 8 pixel blocks) -> 144 weight VGPRs, 32
-//     accumulator registers, everything within the 256 registers a wave may have at two waves per SIMD;
+//     (one per CU, 4 waves = one per SIMD), wave = (32-channel half, 4 of the 8 pixel blocks) -> 144 weight VGPRs, 64
+//     accumulator registers (the eight-wave form, 2 pixel blocks per wave and two waves per SIMD, reads every pixel fragment
+//     from LDS twice as often per MFMA and measured slower);
 //   * a workgroup walks a contiguous run of 16x16-pixel output tiles; the 18x18-pixel input tile with halo is staged ONCE
 //     into LDS (global -> registers -> LDS, double buffered) and all nine taps are read from LDS with ds_read_b128;
 //   * staging goes through registers because it can TRANSFORM: y = prelu(x * scale[n][c] + shift[n][c], alpha[c]) -- the
@@ -15,12 +16,14 @@
 //   * MFMA is v_mfma_f32_32x32x16_bf16 with the 32 "rows" = 2 image rows x 16 columns: the LDS image is pixel-major
 //     (128 B per pixel) with the 16-B chunk XOR-swizzled by (halo column >> 1) & 7 -- conflict-free ds_read_b128 for every
 //     tap shift (the 16-lane groups of a b128 read then see each 16-B slot of the 256-B bank row once);
-//   * the kernel is a hand-laid software pipeline: the 72 MFMAs a wave issues per tile are the clock; every MFMA is followed
+//   * the kernel is a hand-laid software pipeline: the 144 MFMAs a wave issues per tile are the clock; every MFMA is followed
 //     by a slot of "side work" that issues under it (an MFMA holds the vector issue port for 8 of its 32 cycles): the
 //     fragment read of the next stage, the global loads of tile t+1, the stream-out of tile t-1's output image (LDS -> HBM,
-//     + statistics / residual sum) and the transform + LDS write of tile t+1.  The sibling wave of the SIMD fills the stalls
-//     (a first version with one 512-register wave per SIMD ran at 3.5 us per tile with every load / store latency exposed
-//     on top).  Only the accumulator -> LDS epilogue and two barriers per tile are not overlapped;
+//     + statistics / residual sum) and the transform + LDS write of tile t+1.  Only the accumulator -> LDS epilogue and two
+//     barriers per tile are not overlapped.  The element-wise side work is written on register PAIRS (v_pk_fma / v_pk_mul /
+//     v_pk_add, one v_cvt_pk_bf16_f32 per packed dword): 26-28 % fewer VALU instructions per tile in the fused variants than
+//     the scalar form -- worth 5 % on EP 4 and nothing measurable elsewhere: the loop is bound by dependent-issue stalls of its
+//     single wave (SQ_WAIT_INST_ANY 30 %, s_waitcnt 20 % of wave cycles), not by the instruction count;
 //   * accumulators are kept transposed (D[channel][pixel]): a lane owns 4 consecutive channels of a pixel, the epilogue
 //     writes 8-byte packets into an LDS image from which full 128-B pixel rows are streamed out;
 //   * epilogue fusions: bias; per-image sum / sum of squares of the (rounded) output for the InstanceNorm that follows
@@ -45,8 +48,8 @@ constexpr int HS = TS + 2;                // halo tile edge
 constexpr int HPIX = HS * HS;             // 324 halo pixels
 constexpr int INBUF = (HPIX + 1) * 128;   // one input stage (bytes); row 324 is a dump slot for the lanes of the ragged last chunk
 constexpr int NCH = (HPIX * 8 + NT - 1) / NT;  // 16-B chunks a thread stages per tile (11 at 256 threads)
-constexpr int RPP = NT / 8;               // pixel rows one pass of the workgroup covers (64)
-constexpr int NOUT = TS * TS / RPP;       // output-image row groups per thread (4)
+constexpr int RPP = NT / 8;               // pixel rows one pass of the workgroup covers (32)
+constexpr int NOUT = TS * TS / RPP;       // output-image row groups per thread (8)
 constexpr int OPITCH = 144;               // output image pitch (bytes): 16-B aligned, rows 4 banks apart
 constexpr int OUTIMG = TS * TS * OPITCH;  // 36,864 B
 constexpr int OUTBASE = 2 * INBUF;
@@ -139,10 +142,19 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(ADD ? p.ep_add : p.in), 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 4 ? p.ep_c : p.in), 0, p.io_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(EP == 4 ? p.ep_x : p.in), 0, p.io_bytes, 0x00020000);
-  float sc[8], sh[8], al[8];
+  // per-channel coefficients of this thread's chunk column, as register PAIRS: the element-wise work below is written on
+  // f32x2_t so that it issues as v_pk_fma / v_pk_mul / v_pk_add (the fused variants of this kernel are VALU-issue bound:
+  // one wave per SIMD issues the 144 MFMAs of a tile AND its side work)
+  f32x2_t sc[4], sh[4], al[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) sc[e] = 1.f, sh[e] = 0.f, al[e] = 1.f;
-  if ((NORM || RED || EP == 5) && p.n_alpha != nullptr) ld8(p.n_alpha + cc * 8, al);
+  for (int q = 0; q < 4; ++q) sc[q] = (f32x2_t){1.f, 1.f}, sh[q] = (f32x2_t){0.f, 0.f}, al[q] = (f32x2_t){1.f, 1.f};
+  auto ld8p = [&](const float* src, f32x2_t (&v)[4]) {
+    float tmp[8];
+    ld8(src, tmp);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = (f32x2_t){tmp[2 * q], tmp[2 * q + 1]};
+  };
+  if ((NORM || RED || EP == 5) && p.n_alpha != nullptr) ld8p(p.n_alpha + cc * 8, al);
   int n_staged = -1;
 
   auto geo_of = [&](int tl) {
@@ -182,13 +194,9 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   auto xform_part = [&](unsigned vm, int i, int q) {   // NORM: dword q (two channels) of staged chunk i, in place
     if constexpr (NORM) {
       const bool ok = (vm >> i) & 1u;   // zero padding applies AFTER the transform
-      const unsigned w = st[i][q];
-      float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
-      a = a * sc[2 * q] + sh[2 * q];
-      b = b * sc[2 * q + 1] + sh[2 * q + 1];
-      a = a > 0.f ? a : a * al[2 * q];
-      b = b > 0.f ? b : b * al[2 * q + 1];
-      unsigned o = ok ? pack2bf(a, b) : 0u;
+      const f32x2_t z = __builtin_elementwise_fma(unpack2bf(st[i][q]), sc[q], sh[q]);
+      const f32x2_t za = z * al[q];
+      unsigned o = ok ? pack2bf(z.x > 0.f ? z.x : za.x, z.y > 0.f ? z.y : za.y) : 0u;
       // pin the computation to THIS slot: IR-level sinking would otherwise move all four parts down to the LDS write
       // (sched_barrier only fences the machine scheduler)
       asm volatile("" : "+v"(o));
@@ -204,9 +212,9 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   const int oimg = OUTBASE + (t >> 3) * OPITCH + cc * 16;          // + i * RPP * OPITCH
   const int orel0 = ((orow0 * p.W + ocol) * 64 + cc * 8) * 2;      // + i * ORS * W * 128
   const int orstep = ORS * p.W * 128;
-  float bs[8], bss[8], b3[8];   // EP == 1 / 3: sums of this thread's channel chunk, current image
+  f32x2_t bs[4], bss[4], b3[4];   // EP == 1 / 3 / 4: sums of this thread's channel chunk (as pairs), current image
 #pragma unroll
-  for (int e = 0; e < 8; ++e) bs[e] = 0.f, bss[e] = 0.f, b3[e] = 0.f;
+  for (int q = 0; q < 4; ++q) bs[q] = bss[q] = b3[q] = (f32x2_t){0.f, 0.f};
   int n_stats = -1;
   v4u_t ov[NOUT], addv[NOUT], cv[EP == 4 ? NOUT : 1], xv[EP == 4 ? NOUT : 1];
   auto out_mask = [&](const TileGeo& g, bool live) {   // bit i: row group i of this thread lies inside the image
@@ -237,11 +245,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     if constexpr (EP == 2) {
       unsigned o[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float a = __uint_as_float(v[q] << 16) + __uint_as_float(addv[i][q] << 16);
-        const float b = __uint_as_float(v[q] & 0xFFFF0000u) + __uint_as_float(addv[i][q] & 0xFFFF0000u);
-        o[q] = pack2bf(a, b);
-      }
+      for (int q = 0; q < 4; ++q) o[q] = pack2bf(unpack2bf(v[q]) + unpack2bf(addv[i][q]));
       v = v4u_t{o[0], o[1], o[2], o[3]};
     }
     if constexpr (EP == 4) {
@@ -250,30 +254,22 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         // dout = conv + residual gradient, rounded to bf16 as the tensor the reduce pass would have read
-        const unsigned dw = pack2bf(__uint_as_float(v[q] << 16) + __uint_as_float(addv[i][q] << 16),
-                                    __uint_as_float(v[q] & 0xFFFF0000u) + __uint_as_float(addv[i][q] & 0xFFFF0000u));
-        const unsigned w = ok ? dw : 0u, cw = cv[i][q], xw = xv[i][q];
-        float dzs[2];
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-          const int e = 2 * q + hlf;
-          const float d = hlf ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
-          const float c = hlf ? __uint_as_float(cw & 0xFFFF0000u) : __uint_as_float(cw << 16);
-          const float xr = hlf ? __uint_as_float(xw & 0xFFFF0000u) : __uint_as_float(xw << 16);
-          const float z = c * sc[e] + sh[e] + xr;
-          const float dz = z > 0.f ? d : d * al[e];
-          bs[e] += dz;
-          bss[e] += dz * c;
-          b3[e] += d * fminf(z, 0.f);   // = d * z where z <= 0 (two VALU instead of four)
-          dzs[hlf] = dz;
-        }
-        o[q] = pack2bf(dzs[0], dzs[1]);
+        const unsigned dw = pack2bf(unpack2bf(v[q]) + unpack2bf(addv[i][q]));
+        const f32x2_t d = unpack2bf(ok ? dw : 0u), c = unpack2bf(cv[i][q]);
+        const f32x2_t z = __builtin_elementwise_fma(c, sc[q], sh[q]) + unpack2bf(xv[i][q]);
+        const f32x2_t da = d * al[q];
+        const f32x2_t dz = {z.x > 0.f ? d.x : da.x, z.y > 0.f ? d.y : da.y};
+        bs[q] += dz;
+        bss[q] = __builtin_elementwise_fma(dz, c, bss[q]);
+        // d * z where z <= 0 (min + fma instead of compare, select, multiply, add)
+        b3[q] = __builtin_elementwise_fma(d, (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, b3[q]);
+        o[q] = pack2bf(dz);
         asm volatile("" : "+v"(o[q]));
       }
       // pin the sums to THIS slot as well: left free, LLVM sinks the 24 accumulator updates of every row group towards the flush
       // and the kernel spills 220 registers to scratch (4x slower)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bs[e]), "+v"(bss[e]), "+v"(b3[e]));
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bs[q]), "+v"(bss[q]), "+v"(b3[q]));
       v = v4u_t{o[0], o[1], o[2], o[3]};
     }
     __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, voff, 0, 0);
@@ -281,10 +277,8 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       unsigned o[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float a = __uint_as_float(v[q] << 16), b = __uint_as_float(v[q] & 0xFFFF0000u);
-        a = a > 0.f ? a : a * al[2 * q];
-        b = b > 0.f ? b : b * al[2 * q + 1];
-        o[q] = pack2bf(a, b);
+        const f32x2_t a = unpack2bf(v[q]), aa = a * al[q];
+        o[q] = pack2bf(a.x > 0.f ? a.x : aa.x, a.y > 0.f ? a.y : aa.y);
       }
       __builtin_amdgcn_raw_buffer_store_b128(v4u_t{o[0], o[1], o[2], o[3]}, rs_out2, voff, 0, 0);
     }
@@ -292,44 +286,38 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       const bool ok = (om >> i) & 1u;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = ok ? v[q] : 0u;
-        const float a = __uint_as_float(w << 16), b = __uint_as_float(w & 0xFFFF0000u);
-        bs[2 * q] += a; bss[2 * q] += a * a;
-        bs[2 * q + 1] += b; bss[2 * q + 1] += b * b;
+        const f32x2_t a = unpack2bf(ok ? v[q] : 0u);
+        bs[q] += a;
+        bss[q] = __builtin_elementwise_fma(a, a, bss[q]);
       }
     }
     if constexpr (EP == 3) {
       const bool ok = (om >> i) & 1u;   // rows outside the image: d = 0 (the c1 load returned zeros as well)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const unsigned w = ok ? v[q] : 0u, cw = addv[i][q];
-#pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-          const int e = 2 * q + hlf;
-          const float d = hlf ? __uint_as_float(w & 0xFFFF0000u) : __uint_as_float(w << 16);
-          const float c = hlf ? __uint_as_float(cw & 0xFFFF0000u) : __uint_as_float(cw << 16);
-          const float z = c * sc[e] + sh[e];
-          const float dz = z > 0.f ? d : d * al[e];
-          bs[e] += dz;
-          bss[e] += dz * c;
-          b3[e] += d * fminf(z, 0.f);   // = d * z where z <= 0 (two VALU instead of four)
-        }
+        const f32x2_t d = unpack2bf(ok ? v[q] : 0u), c = unpack2bf(addv[i][q]);
+        const f32x2_t z = __builtin_elementwise_fma(c, sc[q], sh[q]);
+        const f32x2_t da = d * al[q];
+        const f32x2_t dz = {z.x > 0.f ? d.x : da.x, z.y > 0.f ? d.y : da.y};
+        bs[q] += dz;
+        bss[q] = __builtin_elementwise_fma(dz, c, bss[q]);
+        b3[q] = __builtin_elementwise_fma(d, (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, b3[q]);   // d * z where z <= 0
       }
       // pinned to this slot (see EP == 4): sunk towards the flush, the accumulator updates cost 60 spilled registers
 #pragma unroll
-      for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bs[e]), "+v"(bss[e]), "+v"(b3[e]));
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bs[q]), "+v"(bss[q]), "+v"(b3[q]));
     }
   };
   auto flush_stats = [&]() {
     // fold the 64 threads that share a chunk column (lanes 8 apart); the 8 waves meet in the atomics (once per image)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float a = bs[e], b = bss[e];
+      float a = bs[e >> 1][e & 1], b = bss[e >> 1][e & 1];
       a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
       b += __shfl_xor(b, 8, 64); b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
       float c3 = 0.f;
       if constexpr (RED) {
-        c3 = b3[e];
+        c3 = b3[e >> 1][e & 1];
         c3 += __shfl_xor(c3, 8, 64); c3 += __shfl_xor(c3, 16, 64); c3 += __shfl_xor(c3, 32, 64);
       }
       if (lane < 8 && n_stats >= 0) {
@@ -337,25 +325,24 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
         atomicAdd(p.stats + ((size_t)p.N + n_stats) * 64 + cc * 8 + e, b);
         if constexpr (RED) atomicAdd(p.stats + ((size_t)2 * p.N + n_stats) * 64 + cc * 8 + e, c3);
       }
-      bs[e] = 0.f;
-      bss[e] = 0.f;
-      b3[e] = 0.f;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bs[q] = bss[q] = b3[q] = (f32x2_t){0.f, 0.f};
   };
   auto stats_image = [&](int n) {   // wave-uniform: called before the first stream-out item of a tile
     if ((EP == 1 || RED) && n != n_stats) {
       if (n_stats >= 0) flush_stats();
       n_stats = n;
       if constexpr (RED) {      // coefficients of z = c1 * scale + shift for the image being streamed out
-        ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
-        ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
+        ld8p(p.n_scale + (size_t)n * 64 + cc * 8, sc);
+        ld8p(p.n_shift + (size_t)n * 64 + cc * 8, sh);
       }
     }
   };
   auto norm_image = [&](int n) {    // wave-uniform: per-image transform coefficients of the tile about to be staged
     if (NORM && n != n_staged) {
-      ld8(p.n_scale + (size_t)n * 64 + cc * 8, sc);
-      ld8(p.n_shift + (size_t)n * 64 + cc * 8, sh);
+      ld8p(p.n_scale + (size_t)n * 64 + cc * 8, sc);
+      ld8p(p.n_shift + (size_t)n * 64 + cc * 8, sh);
       n_staged = n;
     }
   };
