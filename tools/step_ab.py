@@ -130,3 +130,20 @@ for name, v in res.items():
     v = sorted(v)
     c = sorted(cpu[name])
     print(f"{name:12s} median {v[len(v)//2]:.3f} ms  min {v[0]:.3f}  max {v[-1]:.3f}   (host enqueue {c[len(c)//2]:.3f} ms/step)")
+if os.environ.get("GRAPH"):   # the same step as ONE single-stream HIP-graph replay (no lockstep streams, no side stream inside a capture)
+    from xrface.graph import GraphedStep
+    apply([])
+    gs = GraphedStep(lambda: step(), [], warmup=2)
+    for _ in range(3):
+        gs()
+    ts = []
+    for rnd in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            gs()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 4 * 1e3)
+    ts.sort()
+    print(f"{'graph':12s} median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f}  max {ts[-1]:.3f}", flush=True)
+    gs.close()
