@@ -239,74 +239,66 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     }
   };
   auto out_read = [&](int i) { ov[i] = *reinterpret_cast<const v4u_t*>(smem + oimg + i * RPP * OPITCH); };
-  auto out_store = [&](int base, unsigned om, int i) {
-    const unsigned voff = out_voff(base, om, i);
-    v4u_t v = ov[i];
+  // The element-wise work of a row group is cut into four PARTS (dword q = two channels each, results left in place in ov[i]) so
+  // that the pipeline can give every part its own MFMA slot: a slot hides ~7 VALU instructions under its MFMA, a whole row group
+  // of the reducing variants is 60-100 -- issued in one slot it stalls the matrix pipe for that long.
+  v4u_t ov2[EP == 5 ? NOUT : 1];
+  auto out_part = [&](unsigned om, int i, int q) {
+    const bool ok = (om >> i) & 1u;   // rows outside the image contribute nothing to the sums (their loads returned zeros as well)
     if constexpr (EP == 2) {
-      unsigned o[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = pack2bf(unpack2bf(v[q]) + unpack2bf(addv[i][q]));
-      v = v4u_t{o[0], o[1], o[2], o[3]};
+      unsigned o = pack2bf(unpack2bf(ov[i][q]) + unpack2bf(addv[i][q]));
+      asm volatile("" : "+v"(o));
+      ov[i][q] = o;
     }
     if constexpr (EP == 4) {
-      const bool ok = (om >> i) & 1u;
-      unsigned o[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        // dout = conv + residual gradient, rounded to bf16 as the tensor the reduce pass would have read
-        const unsigned dw = pack2bf(unpack2bf(v[q]) + unpack2bf(addv[i][q]));
-        const f32x2_t d = unpack2bf(ok ? dw : 0u), c = unpack2bf(cv[i][q]);
-        const f32x2_t z = __builtin_elementwise_fma(c, sc[q], sh[q]) + unpack2bf(xv[i][q]);
-        const f32x2_t da = d * al[q];
-        const f32x2_t dz = {z.x > 0.f ? d.x : da.x, z.y > 0.f ? d.y : da.y};
-        bs[q] += dz;
-        bss[q] = __builtin_elementwise_fma(dz, c, bss[q]);
-        // d * z where z <= 0 (min + fma instead of compare, select, multiply, add)
-        b3[q] = __builtin_elementwise_fma(d, (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, b3[q]);
-        o[q] = pack2bf(dz);
-        asm volatile("" : "+v"(o[q]));
-      }
-      // pin the sums to THIS slot as well: left free, LLVM sinks the 24 accumulator updates of every row group towards the flush
-      // and the kernel spills 220 registers to scratch (4x slower)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bs[q]), "+v"(bss[q]), "+v"(b3[q]));
-      v = v4u_t{o[0], o[1], o[2], o[3]};
+      // dout = conv + residual gradient, rounded to bf16 as the tensor the reduce pass would have read
+      const unsigned dw = pack2bf(unpack2bf(ov[i][q]) + unpack2bf(addv[i][q]));
+      const f32x2_t d = unpack2bf(ok ? dw : 0u), c = unpack2bf(cv[i][q]);
+      const f32x2_t z = __builtin_elementwise_fma(c, sc[q], sh[q]) + unpack2bf(xv[i][q]);
+      const f32x2_t da = d * al[q];
+      const f32x2_t dz = {z.x > 0.f ? d.x : da.x, z.y > 0.f ? d.y : da.y};
+      bs[q] += dz;
+      bss[q] = __builtin_elementwise_fma(dz, c, bss[q]);
+      // d * z where z <= 0 (min + fma instead of compare, select, multiply, add)
+      b3[q] = __builtin_elementwise_fma(d, (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, b3[q]);
+      unsigned o = pack2bf(dz);
+      // pin the result AND the sums to this slot: left free, LLVM sinks the accumulator updates of every row group towards the
+      // flush and the kernel spills 220 registers to scratch (4x slower)
+      asm volatile("" : "+v"(o), "+v"(bs[q]), "+v"(bss[q]), "+v"(b3[q]));
+      ov[i][q] = o;
     }
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs_out, voff, 0, 0);
-    if constexpr (EP == 5) {   // second output: PReLU of the value just stored (what the next convolution consumes)
-      unsigned o[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2_t a = unpack2bf(v[q]), aa = a * al[q];
-        o[q] = pack2bf(a.x > 0.f ? a.x : aa.x, a.y > 0.f ? a.y : aa.y);
-      }
-      __builtin_amdgcn_raw_buffer_store_b128(v4u_t{o[0], o[1], o[2], o[3]}, rs_out2, voff, 0, 0);
+    if constexpr (EP == 5) {   // second output: PReLU of the value being stored (what the next convolution consumes)
+      const f32x2_t a = unpack2bf(ov[i][q]), aa = a * al[q];
+      unsigned o = pack2bf(a.x > 0.f ? a.x : aa.x, a.y > 0.f ? a.y : aa.y);
+      asm volatile("" : "+v"(o));
+      ov2[i][q] = o;
     }
     if constexpr (EP == 1) {
-      const bool ok = (om >> i) & 1u;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2_t a = unpack2bf(ok ? v[q] : 0u);
-        bs[q] += a;
-        bss[q] = __builtin_elementwise_fma(a, a, bss[q]);
-      }
+      const f32x2_t a = unpack2bf(ok ? ov[i][q] : 0u);
+      bs[q] += a;
+      bss[q] = __builtin_elementwise_fma(a, a, bss[q]);
+      asm volatile("" : "+v"(bs[q]), "+v"(bss[q]));
     }
     if constexpr (EP == 3) {
-      const bool ok = (om >> i) & 1u;   // rows outside the image: d = 0 (the c1 load returned zeros as well)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x2_t d = unpack2bf(ok ? v[q] : 0u), c = unpack2bf(addv[i][q]);
-        const f32x2_t z = __builtin_elementwise_fma(c, sc[q], sh[q]);
-        const f32x2_t da = d * al[q];
-        const f32x2_t dz = {z.x > 0.f ? d.x : da.x, z.y > 0.f ? d.y : da.y};
-        bs[q] += dz;
-        bss[q] = __builtin_elementwise_fma(dz, c, bss[q]);
-        b3[q] = __builtin_elementwise_fma(d, (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, b3[q]);   // d * z where z <= 0
-      }
-      // pinned to this slot (see EP == 4): sunk towards the flush, the accumulator updates cost 60 spilled registers
-#pragma unroll
-      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bs[q]), "+v"(bss[q]), "+v"(b3[q]));
+      const f32x2_t d = unpack2bf(ok ? ov[i][q] : 0u), c = unpack2bf(addv[i][q]);
+      const f32x2_t z = __builtin_elementwise_fma(c, sc[q], sh[q]);
+      const f32x2_t da = d * al[q];
+      const f32x2_t dz = {z.x > 0.f ? d.x : da.x, z.y > 0.f ? d.y : da.y};
+      bs[q] += dz;
+      bss[q] = __builtin_elementwise_fma(dz, c, bss[q]);
+      b3[q] = __builtin_elementwise_fma(d, (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, b3[q]);   // d * z where z <= 0
+      asm volatile("" : "+v"(bs[q]), "+v"(bss[q]), "+v"(b3[q]));   // pinned (see EP == 4)
     }
+  };
+  auto out_emit = [&](int base, unsigned om, int i) {
+    const unsigned voff = out_voff(base, om, i);
+    __builtin_amdgcn_raw_buffer_store_b128(ov[i], rs_out, voff, 0, 0);
+    if constexpr (EP == 5) __builtin_amdgcn_raw_buffer_store_b128(ov2[i], rs_out2, voff, 0, 0);
+  };
+  auto out_store = [&](int base, unsigned om, int i) {   // the whole row group at once (drain after the last tile)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out_part(om, i, q);
+    out_emit(base, om, i);
   };
   auto flush_stats = [&]() {
     // fold the 64 threads that share a chunk column (lanes 8 apart); the 8 waves meet in the atomics (once per image)
@@ -418,26 +410,27 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       } else {
         if constexpr (k >= 1 && k < 1 + 3 * NCH && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
       }
-      // stream-out of tile t-1, row group i: (residual load at 33 + 6 i,) LDS read at RD + ST i, store 3 slots later
-      if constexpr (EP == 4) {
-        // three epilogue loads per row group (residual gradient, tail c2, tail x): only TWO groups are kept in flight (groups 0, 1
-        // load at 20.. / 26.., leave at 61 / 67; groups 2, 3 load at 64.. / 70.., leave at 107 / 113) -- with all four live
-        // the kernel spilled 217 registers to scratch and ran 4x slower
+      // stream-out of tile t-1, row group i of NOUT: (epilogue loads at LD + LS i,) LDS read at RD + ST i, the four element-wise
+      // parts at RD + ST i + OFS + PS q, the store with the last part.  Variants with epilogue loads leave >= 44 slots (~1.5 us)
+      // between a group's loads and its first part and keep 4-5 groups in flight.
+      {
+        constexpr bool HEAVY = EP == 3 || EP == 4;          // reducing epilogues: 16-26 VALU per part -> a part every third slot
+        constexpr int LD = 2, LS = EP == 4 ? 12 : 9;        // EP 4 issues three loads per group (slots LD + LS i + 0 / 1 / 2)
+        constexpr int RD = ADD ? 44 : 36, ST = ADD ? 12 : 8, PS = HEAVY ? 3 : ((ADD || NORM) ? 2 : 1);
+        constexpr int OFS = NORM ? 3 : 2;                   // NORM: parts on odd slots, the on-load transform parts sit on even ones
+        static_assert(RD + ST * (NOUT - 1) + OFS + PS * 3 < NSLOT, "stream-out schedule runs past the tile");
         static_for<0, NOUT>([&](auto I) {
           constexpr int i = decltype(I)::value;
-          constexpr int ld = i == 0 ? 20 : (i == 1 ? 26 : (i == 2 ? 64 : 70));
-          constexpr int rd = i == 0 ? 58 : (i == 1 ? 64 : (i == 2 ? 104 : 110));
-          if constexpr (k == ld) add_load(pbase, om, i);
-          if constexpr (k == ld + 1) tail_load(pbase, om, i, 0);
-          if constexpr (k == ld + 2) tail_load(pbase, om, i, 1);
-          if constexpr (k == rd) out_read(i);
-          if constexpr (k == rd + 3) out_store(pbase, om, i);
+          if constexpr (ADD && k == LD + LS * i) add_load(pbase, om, i);
+          if constexpr (EP == 4 && k == LD + LS * i + 1) tail_load(pbase, om, i, 0);
+          if constexpr (EP == 4 && k == LD + LS * i + 2) tail_load(pbase, om, i, 1);
+          if constexpr (k == RD + ST * i) out_read(i);
+          static_for<0, 4>([&](auto Q) {
+            constexpr int q = decltype(Q)::value;
+            if constexpr (k == RD + ST * i + OFS + PS * q) out_part(om, i, q);
+          });
+          if constexpr (k == RD + ST * i + OFS + PS * 3) out_emit(pbase, om, i);
         });
-      } else {
-      constexpr int RD = ADD ? 69 : 36, ST = ADD ? 6 : 8;
-      if constexpr (ADD && k >= 33 && k < 33 + 6 * NOUT && (k - 33) % 6 == 0) add_load(pbase, om, (k - 33) / 6);
-      if constexpr (k >= RD && k < RD + ST * NOUT && (k - RD) % ST == 0) out_read((k - RD) / ST);
-      if constexpr (k >= RD + 3 && k < RD + 3 + ST * NOUT && (k - RD - 3) % ST == 0) out_store(pbase, om, (k - RD - 3) / ST);
       }
       // transform + LDS write of tile t+1 (the loads left >= 55 slots earlier).  NORM: chunk i is transformed two channels
       // at a time at slots 56 + 8 i + {0, 2, 4, 6} and written at 56 + 8 i + 7; otherwise written at 100 + 4 i
