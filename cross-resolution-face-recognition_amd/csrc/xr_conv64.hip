@@ -40,6 +40,14 @@
 #include <type_traits>
 
 
+// slot table of the on-load transform (NORM): chunk i is transformed at XB + XS i + XP q (q = 0..3) and written at XB + XS i + XW
+#ifndef XR64_XB
+#define XR64_XB 56
+#define XR64_XS 8
+#define XR64_XP 2
+#define XR64_XW 7
+#endif
+
 namespace {
 
 constexpr int NT = 256;
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
   };
   // ---- side work 3: (transform and) write a staged chunk into an input stage
   auto xform_part = [&](unsigned vm, int i, int q) {   // NORM: dword q (two channels) of staged chunk i, in place
+#ifndef XR64_NOXFORM   // timing experiments only (tools/build_variant.sh): the on-load transform's arithmetic switched off
     if constexpr (NORM) {
       const bool ok = (vm >> i) & 1u;   // zero padding applies AFTER the transform
       const f32x2_t z = __builtin_elementwise_fma(unpack2bf(st[i][q]), sc[q], sh[q]);
@@ -202,6 +211,7 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       asm volatile("" : "+v"(o));
       st[i][q] = o;
     }
+#endif
   };
   auto write_chunk = [&](int buf, int i) { *reinterpret_cast<v4u_t*>(smem + buf * INBUF + ldso[i]) = st[i]; };
 
@@ -435,8 +445,11 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
       // transform + LDS write of tile t+1 (the loads left >= 55 slots earlier).  NORM: chunk i is transformed two channels
       // at a time at slots 56 + 8 i + {0, 2, 4, 6} and written at 56 + 8 i + 7; otherwise written at 100 + 4 i
       if constexpr (NORM) {
-        if constexpr (k >= 56 && k < 56 + 8 * NCH && (k - 56) % 8 % 2 == 0) xform_part(vm, (k - 56) / 8, (k - 56) % 8 / 2);
-        if constexpr (k >= 56 && k < 56 + 8 * NCH && (k - 56) % 8 == 7) write_chunk(buf ^ 1, (k - 56) / 8);
+        constexpr int XB = XR64_XB, XS = XR64_XS, XP = XR64_XP, XW = XR64_XW;   // first slot, slots per chunk, part stride, write offset
+        static_assert(XB + XS * (NCH - 1) + XW < NSLOT && 3 * XP < XW && XW < XS + XP, "on-load transform schedule");
+        if constexpr (k >= XB && k < XB + XS * NCH && (k - XB) % XS % XP == 0 && (k - XB) % XS / XP < 4)
+          xform_part(vm, (k - XB) / XS, (k - XB) % XS / XP);
+        if constexpr (k >= XB && k < XB + XS * NCH && (k - XB) % XS == XW) write_chunk(buf ^ 1, (k - XB) / XS);
       } else if constexpr (EP != 4) {
         if constexpr (k >= 100 && k < 100 + 4 * NCH && (k - 100) % 4 == 0) write_chunk(buf ^ 1, (k - 100) / 4);
       }
