@@ -63,7 +63,35 @@ void run(const char* name, int threads, int iters) {
   hipFree(out); hipFree(cyc);
 }
 
-int main() {
+// sustained mode (any argument): the MFMA-only and the MFMA + LDS-read loops for ~4 s each, rate printed per launch batch -- long
+// enough for the package power controller to settle and for tools/probe/power_watch.py-style sampling beside it
+template <int LDSREAD>
+void sustained(const char* name, double secs) {
+  int dev; hipGetDevice(&dev); hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
+  const int grid = prop.multiProcessorCount, threads = 256, iters = 40000;
+  float* out; long long* cyc;
+  hipMalloc(&out, sizeof(float) * grid * threads); hipMalloc(&cyc, sizeof(long long) * grid);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  double total_ms = 0;
+  while (total_ms < secs * 1e3) {
+    hipEventRecord(e0);
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((k<LDSREAD, 4>), dim3(grid), dim3(threads), 65536, 0, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    total_ms += ms;
+    const double flops = 10.0 * iters * 8 * 4 * (threads / 64) * grid * 32768.0;
+    printf("%-40s t=%5.2f s  %7.1f TFLOP/s\n", name, total_ms / 1e3, flops / ms / 1e9);
+    fflush(stdout);
+  }
+  hipFree(out); hipFree(cyc);
+}
+
+int main(int argc, char**) {
+  if (argc > 1) {
+    sustained<0>("sustained: mfma only, 4 acc, 4 waves/CU", 4.0);
+    sustained<1>("sustained: mfma + ds_read_b128 per MFMA", 4.0);
+    return 0;
+  }
   const int it = 4000;
   run<0, 4>("mfma only, 4 accumulators", 256, it);
   run<0, 4>("mfma only, 4 accumulators", 512, it);
