@@ -163,6 +163,9 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     for (int q = 0; q < 4; ++q) v[q] = (f32x2_t){tmp[2 * q], tmp[2 * q + 1]};
   };
   if ((NORM || RED || EP == 5) && p.n_alpha != nullptr) ld8p(p.n_alpha + cc * 8, al);
+  f32x2_t alm1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) alm1[q] = al[q] - (f32x2_t){1.f, 1.f};
   int n_staged = -1;
 
   auto geo_of = [&](int tl) {
@@ -204,8 +207,14 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
     if constexpr (NORM) {
       const bool ok = (vm >> i) & 1u;   // zero padding applies AFTER the transform
       const f32x2_t z = __builtin_elementwise_fma(unpack2bf(st[i][q]), sc[q], sh[q]);
+#ifdef XR64_PRELU_SELECT
       const f32x2_t za = z * al[q];
       unsigned o = ok ? pack2bf(z.x > 0.f ? z.x : za.x, z.y > 0.f ? z.y : za.y) : 0u;
+#else
+      // prelu(z) = z + (alpha - 1) * min(z, 0): two v_min + one packed fma instead of a packed multiply, two compares and two selects
+      // (each compare -> select pair also costs the VCC wait states)
+      unsigned o = ok ? pack2bf(__builtin_elementwise_fma(alm1[q], (f32x2_t){fminf(z.x, 0.f), fminf(z.y, 0.f)}, z)) : 0u;
+#endif
       // pin the computation to THIS slot: IR-level sinking would otherwise move all four parts down to the LDS write
       // (sched_barrier only fences the machine scheduler)
       asm volatile("" : "+v"(o));
