@@ -41,6 +41,9 @@
 
 
 // slot table of the on-load transform (NORM): chunk i is transformed at XB + XS i + XP q (q = 0..3) and written at XB + XS i + XW
+#ifndef XR64_TWO_PHASE
+#define XR64_TWO_PHASE 0   // measured: 7.74 -> 7.69 VALU per MFMA only (the spills are not the staging registers); off
+#endif
 #ifndef XR64_XB
 #define XR64_XB 56
 #define XR64_XS 8
@@ -426,6 +429,12 @@ __global__ __launch_bounds__(NT, 1) void dconv64_kernel(DC64P p) {
         if constexpr (k >= 75 && k < 75 + 3 * (NCH - 6) && (k - 75) % 3 == 0) load_chunk(nbase, vm, 6 + (k - 75) / 3);
         if constexpr (k >= 60 && k < 60 + 4 * 6 && (k - 60) % 4 == 0) write_chunk(buf ^ 1, (k - 60) / 4);
         if constexpr (k >= 122 && k < 122 + 4 * (NCH - 6) && (k - 122) % 4 == 0) write_chunk(buf ^ 1, 6 + (k - 122) / 4);
+      } else if constexpr (NORM && XR64_TWO_PHASE) {
+        // two staging phases here as well: chunk 6 + j is loaded right after chunk j has left for LDS (slot XB + XS j + XW + 1) and
+        // transformed XS * 6 - XW - 1 = 40 slots later -- 24 staging registers live instead of 44, fewer AGPR spill reloads
+        if constexpr (k >= 1 && k < 1 + 3 * 6 && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
+        if constexpr (k >= XR64_XB + XR64_XW + 1 && k < XR64_XB + XR64_XW + 1 + XR64_XS * (NCH - 6) && (k - XR64_XB - XR64_XW - 1) % XR64_XS == 0)
+          load_chunk(nbase, vm, 6 + (k - XR64_XB - XR64_XW - 1) / XR64_XS);
       } else {
         if constexpr (k >= 1 && k < 1 + 3 * NCH && (k - 1) % 3 == 0) load_chunk(nbase, vm, (k - 1) / 3);
       }
