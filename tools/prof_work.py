@@ -41,6 +41,21 @@ with torch.cuda.stream(hp):
         opts = {k: parallel.FusedRMSprop(flats[k], lr=1e-5, weight_decay=1e-5) for k in fhn}
         hm = torch.rand(n, 28, 28, device=dev); par = torch.randint(0, 11, (n, 1, 28, 28), device=dev)
         fn = lambda: steps.fhn_step_fused(fhn, lr, hr, hm, par, optimizers=opts)
+    elif work == "sr":   # SR-variant generators + perceptual IR-50 losses (train_FHN.py:251-308), N = 32 by default
+        from xrface.model import FSRnet_sr
+        nets = {"coarse": FSRnet_sr.Coarse_SR_Network().to(dev), "encoder": FSRnet_sr.Fine_SR_Encoder().to(dev),
+                "prior": FSRnet_sr.Prior_Estimation_Network().to(dev), "decoder": FSRnet_sr.Fine_SR_Decoder().to(dev)}
+        bb = model_irse.IR_50([112, 112]).to(dev).eval()
+        for p_ in bb.parameters():
+            p_.requires_grad_(False)
+        flats = {"coarse": parallel.FlatParams(nets["coarse"].parameters()), "prior": parallel.FlatParams(nets["prior"].parameters()),
+                 "encdec": parallel.FlatParams(list(nets["encoder"].parameters()) + list(nets["decoder"].parameters()))}
+        opts = {k: parallel.FusedAdam(f, lr=1e-4, betas=(0.5, 0.999), weight_decay=1e-5) for k, f in flats.items()}
+        hm = torch.rand(n, 112, 112, device=dev); par = torch.randint(0, 13, (n, 1, 112, 112), device=dev)
+        def fn():
+            for o in opts.values():
+                o.zero_grad()
+            steps.fhn_perceptual_step(nets, bb, lr, hr, hm, par, optimizers=opts)
     else:
         model = model_irse.IR_SE_50([112, 112]).to(dev).train()
         flat = parallel.FlatParams(model.parameters_in_execution_order())
