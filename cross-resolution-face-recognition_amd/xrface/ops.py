@@ -621,7 +621,11 @@ def leave2d(buf):
 # ------------------------------------------------------------------------------------------------- convolution
 def _bias_grad(dy, K):
     N, Ho, Wo, Kp = dy.shape
-    if _cfg.get("deterministic") and N > 1:    # one block per image, the images summed in a fixed order
+    # One group over all N * Ho * Wo rows sends every block's 2 * Kp atomics to the same few cache lines: 784 blocks on a
+    # [32][56][56][64] gradient took 31 us (12.8 MB: 5 us of streaming) -- the SR-variant bottlenecks have three biased
+    # convolutions each.  Per-image sums (the InstanceNorm geometry: blocks of one image meet in their own lines) + a fold of N
+    # rows: ~11 us.  Also the deterministic form: one block per image, the images summed in a fixed order.
+    if N > 1 and (_cfg.get("deterministic") or N * Ho * Wo >= 16384):
         sums = zeros_f32((2, N, Kp), dy.device)
         lib.xr_group_stats(dt(dy), ptr(dy), ptr(sums), N, Ho * Wo, Kp, stream())
         out = torch.empty((Kp,), dtype=torch.float32, device=dy.device)
