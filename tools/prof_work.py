@@ -11,7 +11,7 @@ from xrface.loss.loss import CrossEntropyLoss
 from xrface.model import FSRnet, model_irse
 
 dev = torch.device("cuda:0")
-xrface.set_compute_dtype(torch.bfloat16)
+xrface.set_compute_dtype({"bf16": torch.bfloat16, "fp32": torch.float32, "fp32x2": "fp32x2"}[os.environ.get("MODE", "bf16")])   # MODE=bf16|fp32|fp32x2
 work = os.environ.get("WORK", "c4")
 n = int(os.environ.get("N", 256 if work != "c3" else 128))
 nsteps = int(os.environ.get("STEPS", 3))
