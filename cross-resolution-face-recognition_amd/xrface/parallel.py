@@ -92,8 +92,10 @@ class BucketedAllReduce:
     signals more often than learned after its bucket has gone out makes ``finish()`` raise (and re-learn) instead of
     silently averaging incomplete gradients.  ``overlap=False`` defers every launch to ``finish()``."""
 
-    def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True, force: bool = False):
+    def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True, force: bool = False,
+                 comm_stream: bool = True):
         self.flat = flat
+        self.comm_stream, self._comm = comm_stream, None
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
@@ -138,11 +140,27 @@ class BucketedAllReduce:
         self._works = []
 
     def _launch(self, b):
-        ops.join_side_stream()   # weight gradients computed on the side stream must have landed in the bucket
         self._launched[b] = True
         self.launch_order.append(b)
         lo, hi, _ = self.buckets[b]
         buf = self.flat.grad[lo:hi]
+        if buf.is_cuda and self.comm_stream:
+            # The bucket holds gradients written by the stream backward runs on AND by the weight-gradient side stream, which runs
+            # behind it by design.  Joining the side stream into the backward stream here (once per bucket: 8 times per IR-SE-50
+            # step) would stall backward until the weight gradients caught up; instead a launcher stream waits for both and the
+            # collective is enqueued from there -- backward never waits, finish() makes the optimizer's stream wait for the works.
+            cur = torch.cuda.current_stream(buf.device)
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(buf.device)
+            self._comm.wait_stream(cur)
+            with torch.cuda.stream(self._comm):
+                ops.join_side_stream()
+                self._enqueue(buf)
+            return
+        ops.join_side_stream()   # weight gradients computed on the side stream must have landed in the bucket
+        self._enqueue(buf)
+
+    def _enqueue(self, buf):
         if self.backend == "nccl":
             self._works.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
         else:
