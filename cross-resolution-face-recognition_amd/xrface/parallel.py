@@ -93,7 +93,7 @@ class BucketedAllReduce:
     silently averaging incomplete gradients.  ``overlap=False`` defers every launch to ``finish()``."""
 
     def __init__(self, flat: FlatParams, bucket_mb: float = 24.0, group=None, overlap: bool = True, force: bool = False,
-                 comm_stream: bool = True):
+                 comm_stream: bool = True, tail_mb: float = 1.0):
         self.flat = flat
         self.comm_stream, self._comm = comm_stream, None
         self.group = group
@@ -111,6 +111,19 @@ class BucketedAllReduce:
             if hi - lo >= cap or i == 0:
                 self.buckets.append((lo, hi, tuple(cur)))
                 hi, cur = lo, []
+        # The last bucket (the first layers) completes with the very last gradient of the backward pass: its collective is the one
+        # nothing hides.  Cut it so that only ~tail_mb wait for the end; the rest of it leaves a few layers earlier.
+        tcap = int(tail_mb * (1 << 20) / 4)
+        if tcap > 0 and self.buckets:
+            lo, hi, idx = self.buckets[-1]
+            asc = sorted(idx)
+            k = 0
+            while k < len(asc) - 1 and flat.offsets[asc[k + 1]] - lo <= tcap:
+                k += 1
+            if k + 1 < len(asc):
+                cut = flat.offsets[asc[k + 1]]
+                self.buckets[-1] = (cut, hi, tuple(i for i in idx if i > asc[k]))
+                self.buckets.append((lo, cut, tuple(i for i in reversed(asc[:k + 1]))))
         self.bucket_of = {}
         for b, (_, _, idx) in enumerate(self.buckets):
             for i in idx:

@@ -192,7 +192,8 @@ def test_bench_two_rank_rehearsal_prints_one_line():
         assert "error" not in sec[k], sec[k]
         assert sec[k]["n_gpus"] == 2 and sec[k]["per_gpu_batch"] == nb and sec[k]["ms_per_step"] > 0
         assert "data parallel" in sec[k]["workload"] and "cpu_baseline" not in sec[k]
-        assert abs(sec[k]["images_per_s"] - 2 * nb / (sec[k]["ms_per_step"] * 1e-3)) <= 0.02 * sec[k]["images_per_s"]
+        # (both numbers are rounded in the line: images_per_s to 0.1, ms_per_step to 0.01 -- over gloo the rehearsal runs at ~1.5 images/s)
+        assert abs(sec[k]["images_per_s"] - 2 * nb / (sec[k]["ms_per_step"] * 1e-3)) <= max(0.02 * sec[k]["images_per_s"], 0.06)
 
 
 @pytest.mark.timeout(300)
