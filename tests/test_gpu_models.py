@@ -185,9 +185,12 @@ def test_ir_backbone_eval_and_train(tag, se):
 def test_irse50_train_step_at_a_ragged_medium_batch_matches_the_live_oracle():
     """The fixtures pin the IR-SE-50 step at N = 8; the full-size (N = 256) tests are property checks of the bf16 path against the
     fp32 path.  In between: N = 40 (not a multiple of any tile height: 40 x 12 544 .. 40 x 49 rows, ragged last tiles in every GEMM,
-    two and a half 16-image groups in the per-image passes) against the CPU oracle run here on the same weights and inputs --
-    output, loss, every parameter gradient and the BatchNorm running statistics, in the fp32 parity mode."""
+    two and a half 16-image groups in the per-image passes) against the CPU oracle run here on the same weights and inputs, in fp32
+    AND in fp64 -- output, loss and BatchNorm running statistics against the fp32 oracle at the north-star 1e-3; every parameter
+    gradient against the fp64 oracle, bounded as everywhere in this file by K_SPREAD x the fp32 oracle's OWN distance from fp64 on the
+    same tensors (measured in the test: ~6e-3 of max-abs on conv1 of units 9 and 21) and never by more than KD_GRAD_TOL."""
     import xrface
+    from oracle.grad_conditioning import _to, spread
     from xrface.loss.loss import CrossEntropyLoss
     from xrface.model import model_irse
     from xrface.steps import teacher_step
@@ -197,22 +200,29 @@ def test_irse50_train_step_at_a_ragged_medium_batch_matches_the_live_oracle():
     x = G.synth_faces(n, 112, seed=5, start=300)
     tgt = G.synth_labels(n, 512, seed=6)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    ref_loss, ref_emb, ref_g, ref_stats = R.teacher_step_grads(sd, x, tgt, se=True)
+    ref_loss, ref_emb, g32, ref_stats = R.teacher_step_grads(sd, x, tgt, se=True)
+    _, _, g64, _ = R.teacher_step_grads(_to(sd, torch.float64), x.double(), tgt, se=True)
+    own = spread(g32, g64)                      # the fp32 oracle against fp64: what "exact" means for these gradients
     net.train()
     net.output_layer[1].p = 0.0
-    loss, out = teacher_step(net, x.to(DEV), tgt.to(DEV), criterion=CrossEntropyLoss())
+    # deterministic summation order: on these tensors the order of the fp32 atomics alone moves the HIP result between 5e-3 and 1e-2
+    # of max-abs from run to run (conditioning ~1e5 x fp32 epsilon) -- the comparison should not depend on the scheduler
+    xrface.set_deterministic(True)
+    try:
+        loss, out = teacher_step(net, x.to(DEV), tgt.to(DEV), criterion=CrossEntropyLoss())
+        torch.cuda.synchronize()
+    finally:
+        xrface.set_deterministic(False)
     e_out = rel(out, ref_emb)
     assert e_out < TOL, f"train-mode output {e_out:.2e}"
     assert abs(loss.item() - float(ref_loss)) <= TOL * abs(float(ref_loss))
-    g = grads_by_name(net)
-    gmax = max(float(v.abs().max()) for v in ref_g.values())
-    worst = ("", 0.0)
-    for name, rg in ref_g.items():
-        e = float((g[name].detach().float().cpu() - rg).abs().max() / max(float(rg.abs().max()), 1e-3 * gmax))
-        if e > worst[1]:
-            worst = (name, e)
-    print(f"N={n}: output {e_out:.2e}, worst gradient {worst[0]} {worst[1]:.2e}")
-    assert worst[1] < GRAD_TOL, worst
+    g = {k: v.detach().float().cpu() for k, v in grads_by_name(net).items()}
+    hip = spread(g, g64)
+    tol = min(KD_GRAD_TOL, max(K_SPREAD * own["worst"], 2e-3))
+    print(f"N={n}: output {e_out:.2e}; gradients vs fp64: HIP worst {hip['worst']:.2e} ({hip['worst_tensor']}), "
+          f"fp32 oracle worst {own['worst']:.2e} ({own['worst_tensor']}), bound {tol:.2e}; cosine {hip['cosine']:.8f}")
+    assert hip["worst"] <= tol, (hip["worst_tensor"], hip["worst"], own["worst"])
+    assert hip["cosine"] > 1 - 1e-5
     new_sd = net.state_dict()
     for k, v in ref_stats.items():
         if k in new_sd and new_sd[k].dtype.is_floating_point:
