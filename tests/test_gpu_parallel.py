@@ -183,7 +183,8 @@ def test_bench_two_rank_rehearsal_prints_one_line():
     assert len(lines) == 1, r.stdout[-2000:]
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 32 and line["scaling"] == "weak"
-    assert line["value"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    # (value is printed with one decimal: at the rehearsal's ~12 images/s over gloo the rounding alone is up to 0.4 %)
+    assert line["value"] > 0 and abs(line["value"] - 32 / (line["ms_per_step"] * 1e-3)) < max(1e-3 * line["value"], 0.06)
     assert "cpu_baseline" not in line                                   # rank-0-at-N=1 leg only
     # the multi-GPU configurations (BASELINE configs[3], [2]) are timed in their data-parallel form, all-reduce inside the step
     sec = {e["workload"][:2]: e for e in line["secondary"]}
