@@ -703,6 +703,9 @@ def main():
                           "achieved_tflops": round(step_tflops, 1), "frac_of_bf16_peak_per_gpu":
                               round(step_tflops / world / PEAK_BF16_TFLOPS, 4)},
         }
+        sh = step_roofline("c2", ms, args.batch) if args.dtype == "bf16" else None   # HBM bytes of the whole step (PMC, committed profile)
+        if sh is not None:
+            line["step_hbm"] = sh
         if dom is not None:
             evs = probe["events"]
             in_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs) if evs else dom["avg_ms"]
