@@ -264,7 +264,8 @@ extern "C" int xr_conv64_wgrad(const void* in, const void* dy, float* slabs, int
   p.N = N; p.H = H; p.W = W;
   p.rows_total = N * H;
   p.io_bytes = (unsigned)((long long)N * H * W * 128);
-  int grid = cu_count();
+  int grid = cu_count() - (int)g_tune[17];   // knob 17: see xr_conv_wgrad_rows
+  if (grid < 8) grid = 8;
   if (grid > max_slabs) grid = max_slabs;
   if (grid > p.rows_total) grid = p.rows_total;
   p.rows_per_wg = cdiv(p.rows_total, grid);

@@ -306,7 +306,10 @@ extern "C" int xr_conv_wgrad_rows(const void* in, const void* dy, float* slabs, 
   p.tiles = (K / 64) * (C / 64);
   p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
   hipStream_t st = (hipStream_t)stream;
-  const int ncu = cu_count_rows();
+  // knob 17: compute units the persistent side-stream kernels leave free (their workgroups hold a CU for the whole launch; a short
+  // kernel of the backward chain that arrives meanwhile otherwise waits for one of them to retire)
+  int ncu = cu_count_rows() - (int)g_tune[17];
+  if (ncu < 8) ncu = 8;
   if (stride == 1) {
     // rows per step: measured per plan (tools/wgrad_rows_bench.py): 14 / 7 / 3 rows beat 16 / 8 / 4 on the narrow plans, two rows per
     // step beat one on the 112-wide plan (966 vs 777 TFLOP/s at 64 -> 64, batch 256: half the barriers per MFMA)
