@@ -31,8 +31,12 @@ from . import ops
 
 
 class GraphedStep:
-    def __init__(self, fn, example_inputs, warmup: int = 3):
-        """fn(*tensors) -> tensor | tuple of tensors | None runs one full step; it must not synchronise with the host."""
+    def __init__(self, fn, example_inputs, warmup: int = 3, side_stream: bool = False):
+        """fn(*tensors) -> tensor | tuple of tensors | None runs one full step; it must not synchronise with the host.
+        side_stream=True keeps the weight-gradient side stream inside the capture: its fork (an event recorded on the capturing
+        stream) and its join (the end-of-backward callback, the optimizers) become the two branches of the graph.  Measured
+        slower than both the eager two-stream step and the single-stream graph at batch 256; kept for
+        small / chunked batches where the overlap matters more than the branch bookkeeping of the graph runtime."""
         assert all(t.is_cuda for t in example_inputs), "GraphedStep: inputs must be device tensors"
         self.graph = None
         self.static_out = None
@@ -65,6 +69,10 @@ class GraphedStep:
         graph = torch.cuda.CUDAGraph()
         ops._zpools.clear()
         ops._graph["capturing"] = True
+        ops._graph["side_ok"] = bool(side_stream)
+        # the device is idle (synchronised above): forget the warm-up's fork / join history, so that a join issued before the first
+        # captured fork is a no-op instead of a dependency of the capturing stream on a stream that is not part of the capture
+        ops._side["seq"], ops._side["joined"] = 0, {}
         try:
             with torch.cuda.graph(graph):
                 self.tick.add_(1)
@@ -81,7 +89,11 @@ class GraphedStep:
             raise
         finally:
             ops._graph["capturing"] = False
+            ops._graph["side_ok"] = False
+            ops._side["seq"], ops._side["joined"] = 0, {}
             ops._zpools.clear()   # the slab captured above belongs to the graph's memory pool
+            if side_stream and ops._side["stream"] is not None:   # every stream / event the capture touched lives as long as the graph
+                self._streams += [ops._side["stream"], ops._side["ev"]]
         self.graph = graph
 
     def __call__(self, *inputs):

@@ -134,7 +134,14 @@ _zpools = {}     # one pool per stream: a slab is zeroed by a memset on the stre
 
 # HIP-graph capture state (xrface.graph.GraphedStep): while a step is being captured, the zero slab is re-created inside the
 # capture (so every replay re-zeroes it) and dropout reads a device-side step counter that the graph itself increments
-_graph = {"capturing": False, "tick": None, "tick_ref": 0}
+_graph = {"capturing": False, "tick": None, "tick_ref": 0, "side_ok": False}
+
+
+def _one_stream():
+    """A HIP-graph capture keeps everything on the capturing stream unless it was opened with side_stream=True (graph.GraphedStep):
+    the weight-gradient fork / join is then captured as two branches of the graph."""
+    return _graph["capturing"] and not _graph["side_ok"]
+
 
 
 def _zpool_of(device):
@@ -306,7 +313,7 @@ def _wgrad(w, x, dy, N, H, W, Cp, Ho, Wo, K, R, S, stride, pad, transposed, Kp, 
     # direct forward / input-gradient kernels of the main stream (120 KB) the two only take turns on the CUs, so in the FHN step
     # alone the side stream buys nothing for it (C3 N = 128: 36.41 vs 36.42 ms in the interleaved A/B) -- in the composed step it
     # still overlaps the IR-SE-50 chains: C4 105.2 vs 106.7 ms, so it stays on)
-    if tgt is not None and _cfg["wgrad_stream"] and not _graph["capturing"] and (not d64 or _cfg["wgrad64_stream"]):
+    if tgt is not None and _cfg["wgrad_stream"] and not _one_stream() and (not d64 or _cfg["wgrad64_stream"]):
         dev = x.device
         side = _side_fork(dev)     # side stream now waits for everything enqueued on the current stream (x, dy, zeroed grads)
         sh = side.cuda_stream      # launch on the side stream by handle: no current-stream switch on the host
@@ -1376,7 +1383,7 @@ def _resblock_abi_ok(x):
 def _side_for_block(dev):
     """(side stream handle, fork event handle) for xr_resblock_bwd, or (None, None) when the weight gradients stay on the main
     stream; the C side records the event and makes the side stream wait, _side_done() does the bookkeeping afterwards."""
-    if not (_cfg["wgrad_stream"] and _cfg["wgrad64_stream"]) or _graph["capturing"]:
+    if not (_cfg["wgrad_stream"] and _cfg["wgrad64_stream"]) or _one_stream():
         return None, None, None
     if _side["stream"] is None or _side["dev"] != dev:
         _side_fork(dev)            # creates stream + event (and records the event once: a HIP event exists after its first record)
@@ -1920,7 +1927,7 @@ class _BnSeAdd(Function):
             dw1 = t1 if t1 is not None else zeros_f32((Cr, C, 1, 1), dev)
             dw2 = t2 if t2 is not None else zeros_f32((C, Cr, 1, 1), dev)
 
-            on_side = t1 is not None and t2 is not None and _cfg["wgrad_stream"] and not _graph["capturing"]
+            on_side = t1 is not None and t2 is not None and _cfg["wgrad_stream"] and not _one_stream()
             side = _side_fork(dev) if on_side else None      # parameter gradients: off the critical path
             sh = side.cuda_stream if on_side else stream()
             lib.xr_small_atb(ptr(dhid), ptr(pooled), ptr(dw1), N, Cr, C, 1.0 / HW, 1, sh)
@@ -2061,7 +2068,7 @@ class _IrSeUnit(Function):
         dse2 = (ts2 if ts2 is not None else zeros_f32(tuple(se2.shape), dev)) if want else None
         all_direct = want and all(t is not None for t in (tw1, tw2, ts1, ts2))
         side, side_h, ev_h = (None, None, None)
-        if all_direct and _cfg["wgrad_stream"] and not _graph["capturing"]:
+        if all_direct and _cfg["wgrad_stream"] and not _one_stream():
             if _side["stream"] is None or _side["dev"] != dev:
                 _side_fork(dev)
             side, side_h, ev_h = _side["stream"], _side["stream"].cuda_stream, _side["ev"].cuda_event

@@ -218,6 +218,72 @@ def test_graph_capture_with_side_stream_enabled():
         xrface.set_compute_dtype(torch.float32)
 
 
+def test_graph_capture_keeps_the_side_stream_and_replays_equal_eager_steps():
+    """GraphedStep(side_stream=True): the weight-gradient fork / join is captured as two branches of the graph.  In the deterministic
+    mode (every fp32 sum in a fixed order) concurrency cannot change a result, so N replays must leave exactly the parameters N
+    eager two-stream steps leave -- bit for bit -- and the captured graph must really contain side-stream work."""
+    import xrface
+    from xrface import ops, parallel
+    from xrface.graph import GraphedStep
+    from xrface.loss.loss import CrossEntropyLoss
+    from xrface.model import model_irse
+
+    xrface.set_compute_dtype(torch.bfloat16)
+    xrface.set_deterministic(True)
+    old = ops._cfg["wgrad_stream"]
+    ops._cfg["wgrad_stream"] = 1
+    try:
+        torch.manual_seed(4)
+        m_e = model_irse.IR_SE_50([112, 112]).to(DEV).train()
+        m_e.output_layer[1].p = 0.0                      # dropout off: the two runs draw from different counters
+        m_g = copy.deepcopy(m_e)
+        crit = CrossEntropyLoss()
+        y = torch.randint(0, 512, (16,), device=DEV)
+        x = _faces(16, 9)
+
+        def make(model):
+            flat = parallel.FlatParams(model.parameters_in_execution_order())
+            opt = parallel.FusedSGD(flat, lr=0.01, momentum=0.9, weight_decay=5e-4)
+            lbuf = torch.zeros((), device=DEV)
+
+            def step(xx):
+                opt.zero_grad()
+                loss = crit(model(xx), y)
+                loss.backward()
+                opt.step()
+                lbuf.copy_(loss.detach())
+                return lbuf
+            return flat, step
+        flat_e, step_e = make(m_e)
+        flat_g, step_g = make(m_g)
+        forks = [0]
+        done0 = ops._side_done
+
+        def counting_done(side, tensors):
+            if ops._graph["capturing"]:
+                forks[0] += 1
+            return done0(side, tensors)
+        ops._side_done = counting_done
+        try:
+            gs = GraphedStep(step_g, [x], warmup=2, side_stream=True)
+        finally:
+            ops._side_done = done0
+        assert forks[0] > 20, f"only {forks[0]} groups of side-stream launches inside the capture"
+        for _ in range(2):                                # the eager twin takes the warm-up's two steps
+            step_e(x)
+        for _ in range(3):
+            le = float(step_e(x))
+            lg = float(gs(x))
+            assert le == lg, (le, lg)
+        torch.cuda.synchronize()
+        assert torch.equal(flat_e.flat, flat_g.flat)
+        gs.close()
+    finally:
+        ops._cfg["wgrad_stream"] = old
+        xrface.set_deterministic(False)
+        xrface.set_compute_dtype(torch.float32)
+
+
 def test_eval_between_replays_sees_current_weights_and_statistics():
     """train/validate loop around a captured step: replays move the parameters and the BatchNorm running statistics without
     bumping any tensor version, so the host-side caches (weight packs, eval-mode BatchNorm scale/shift) must be invalidated

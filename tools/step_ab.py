@@ -133,7 +133,7 @@ for name, v in res.items():
 if os.environ.get("GRAPH"):   # the same step as ONE single-stream HIP-graph replay (no lockstep streams, no side stream inside a capture)
     from xrface.graph import GraphedStep
     apply([])
-    gs = GraphedStep(lambda: step(), [], warmup=2)
+    gs = GraphedStep(lambda: step(), [], warmup=2, side_stream=bool(os.environ.get("GRAPH_SIDE")))   # GRAPH_SIDE=1: keep the fork / join
     for _ in range(3):
         gs()
     ts = []
@@ -145,5 +145,5 @@ if os.environ.get("GRAPH"):   # the same step as ONE single-stream HIP-graph rep
         torch.cuda.synchronize()
         ts.append((time.perf_counter() - t0) / 4 * 1e3)
     ts.sort()
-    print(f"{'graph':12s} median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f}  max {ts[-1]:.3f}", flush=True)
+    print(f"{'graph+side' if os.environ.get('GRAPH_SIDE') else 'graph':12s} median {ts[len(ts)//2]:.3f} ms  min {ts[0]:.3f}  max {ts[-1]:.3f}", flush=True)
     gs.close()
